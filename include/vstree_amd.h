@@ -1,0 +1,262 @@
+/*
+  vstree_amd.h -- C ABI of the MI355X-native Vmengine query path.
+
+  One shared library (vstree_amd/libvstree_amd.so, HIP for gfx950 inside)
+  replaces the reference's CPU implementation of
+
+    vmatch -complete -q Q IDX          exact complete matches
+    vmatch -l L -q Q IDX               maximal exact matches (MEM)
+    vmatch -mum [cand] -l L -q Q IDX   maximal unique matches / candidates
+    vmatch -mum -l L IDX               MUMs when the queries are in the index
+
+  on the enhanced suffix array mkvtree writes.  Everything here is plain C:
+  pointers, sizes, opaque handles; no HIP or torch types.  Each entry point
+  names the reference interface it stands in for (paths relative to
+  /root/reference/src); INTEGRATION.md shows the few lines of C a Vmatch
+  maintainer adds so that findcompletematches / findquerymatches /
+  findmaximaluniquematches of Vmengine/vmengineexport.h:4-81 call these.
+
+  Conventions (the reference's, include/errordef.h:45-82): functions return
+  0 on success and a negative code on error; the message is then available
+  from vsa_messagespace().  All calls on one vsa_index must come from one
+  thread at a time, like the reference's engine.
+*/
+#ifndef VSTREE_AMD_H
+#define VSTREE_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSA_SEPARATOR 255u /* include/chardef.h:19 */
+#define VSA_WILDCARD  254u /* include/chardef.h:25 */
+#define VSA_UNDEFBWT  253u /* include/chardef.h:31,50 */
+#define VSA_NO_SUBST  0xFFFFFFFFu
+
+/* ---- errors: messagespace(), include/errordef.h:13 -------------------- */
+
+const char *vsa_messagespace(void);
+
+/* ---- the index: Virtualtree, include/virtualdef.h:186-219 ------------- */
+
+/*
+  Raw tables of one index exactly as mkvtree -allout writes them and
+  mapvirtualtreeifyoucan (kurtz-basic/readvirt.c:776-907) maps them: host
+  pointers, host endianness, no headers.  integersize is the bit width of
+  the entries of suf, bck and llv (32 or 64, the `integersize=` line of the
+  .prj file, Mkvtree/mkvprocess.c:403-504).  bwt may be NULL unless
+  vsa_findmaximaluniquematches is used.
+*/
+typedef struct
+{
+  uint64_t totallength;     /* multiseq.totallength                     */
+  uint32_t prefixlength;    /* Virtualtree.prefixlength                 */
+  uint32_t numofchars;      /* alpha.mapsize - 1 (4 for DNA)            */
+  uint32_t integersize;     /* 32 or 64                                 */
+  uint64_t largelcpvalues;  /* pairs in llv                             */
+  const uint8_t *tis;       /* [totallength]   alphabet-mapped text     */
+  const void *suf;          /* [totallength+1] suffix array             */
+  const uint8_t *lcp;       /* [totallength+1] min(lcp, 255)            */
+  const void *llv;          /* [2*largelcpvalues] (index, value) pairs  */
+  const void *bck;          /* [2*numofchars^prefixlength] (left, mid)  */
+  const uint8_t *bwt;       /* [totallength+1] or NULL                  */
+  /* indexes built with mkvtree -db G -q Q: position of the separator
+     between database and queries (getqueryseppos,
+     kurtz-basic/multiseq-adv.c:1005); ignored if hasindexedqueries == 0 */
+  uint64_t querysepposition;
+  int hasindexedqueries;
+} vsa_tables;
+
+typedef struct vsa_index vsa_index; /* ESA resident in one GPU's HBM */
+
+/* uploads the tables to HIP device `device`; the host tables are not
+   referenced after return */
+int vsa_index_from_tables(const vsa_tables *tables, int device,
+                          vsa_index **index);
+
+/* reads indexname.prj and maps indexname.{tis,suf,lcp,llv,bck,bwt} like
+   mapvirtualtreeifyoucan(…, TISTAB|SUFTAB|LCPTAB|BCKTAB[|BWTTAB])
+   (kurtz-basic/readvirt.c:776, demand: Vmatch/mapdemand.c:174-191) */
+int vsa_index_open(const char *indexname, int device, vsa_index **index);
+
+void vsa_index_close(vsa_index *index);
+
+typedef struct
+{
+  uint64_t totallength, numofcodes, largelcpvalues, device_bytes;
+  uint32_t prefixlength, numofchars, device_integersize;
+  int device, hasindexedqueries, hasbwt;
+} vsa_index_info;
+
+int vsa_index_getinfo(const vsa_index *index, vsa_index_info *info);
+
+/*
+  Builds the tables on the GPU from an alphabet-mapped text that is already
+  on the host (symbols 0..numofchars-1, VSA_WILDCARD, VSA_SEPARATOR), with
+  the semantics of mkvtree -pl <prefixlength> -tis -suf -lcp -bck -bwt
+  (Mkvtree/mkvprocess.c:875-1089; suffix order Mkvtree/bese.c:27-49,602).
+  prefixlength 0 selects vm_recommendedprefixlength (kurtz/detpfxlen.c:52).
+*/
+int vsa_index_build(const uint8_t *tis, uint64_t totallength,
+                    uint32_t numofchars, uint32_t prefixlength, int device,
+                    vsa_index **index);
+
+/* same, for a text that already lives in device memory (bench.py) */
+int vsa_index_build_device(const void *device_tis, uint64_t totallength,
+                           uint32_t numofchars, uint32_t prefixlength,
+                           int device, vsa_index **index);
+
+/* copies the device tables back to host buffers sized by the caller from
+   vsa_index_getinfo (entries of suf/bck/llv have device_integersize bits);
+   NULL pointers are skipped */
+int vsa_index_download(const vsa_index *index, uint8_t *tis, void *suf,
+                       uint8_t *lcp, void *llv, void *bck, uint8_t *bwt);
+
+/* ---- queries: Queryinfo.multiseq, Vmengine/mparms.h:73-84 ------------- */
+
+typedef struct vsa_queries vsa_queries;
+
+/*
+  nq query sequences given as (start, length) pairs into one buffer of
+  alphabet-mapped symbols -- the layout of a reference Multiseq: sequences
+  separated by VSA_SEPARATOR, start[i] = markpos[i-1]+1
+  (include/multidef.h:113-133, kurtz-basic/multiseq.c:129-166).
+*/
+int vsa_queries_from_host(const uint8_t *symbols, uint64_t nsymbols,
+                          const uint64_t *start, const uint64_t *length,
+                          uint64_t nq, int device, vsa_queries **queries);
+
+/* nq queries of equal length m stored back to back in device memory
+   (device_symbols[i*m .. i*m+m)); the buffer is copied */
+int vsa_queries_from_device(const void *device_symbols, uint64_t nq,
+                            uint32_t m, int device, vsa_queries **queries);
+
+void vsa_queries_free(vsa_queries *queries);
+
+/* ---- matches ---------------------------------------------------------- */
+
+/* field for field the reference's MUMcandidate (include/mumcand.h:17-23);
+   what processexactquerymatch(info, l, i, queryseq, querystart)
+   (Vmengine/procexqu.c:17-64) receives for one match */
+typedef struct
+{
+  uint64_t length;     /* length1 = length2                           */
+  uint64_t dbstart;    /* position1: absolute position in the index   */
+  uint64_t queryseq;   /* seqnum2                                     */
+  uint64_t querystart; /* relpos2                                     */
+} vsa_match;
+
+typedef struct vsa_result vsa_result; /* match list resident in HBM */
+
+typedef struct
+{
+  uint64_t count;          /* matches                                     */
+  uint64_t sumlength;      /* sum of match lengths ("bp matched")         */
+  uint64_t searches;       /* bucket lookups + binary searches performed  */
+  uint64_t candidates;     /* MUM candidates before the query-side filter */
+  double search_kernel_ms; /* HIP-event time of the dominant search kernel */
+  double total_device_ms;  /* HIP-event time of the whole call            */
+} vsa_stats;
+
+uint64_t vsa_result_count(const vsa_result *result);
+int vsa_result_getstats(const vsa_result *result, vsa_stats *stats);
+/* copies min(count, capacity) matches to the host, in reference order */
+int vsa_result_fetch(const vsa_result *result, vsa_match *matches,
+                     uint64_t capacity);
+const void *vsa_result_device_matches(const vsa_result *result);
+void vsa_result_free(vsa_result *result);
+
+/* ---- the engine: Vmengine/vmengineexport.h:4-81 ----------------------- */
+
+/*
+  findcompletematches (Vmengine/fcomplete.c:263-321) for exact matching on
+  the index (decidefcm -> findexactcompletematchesindex,
+  Vmengine/exactcompl.c:168-239).  Order: query order, within a query suffix
+  array order.  A query shorter than prefixlength is the reference's hard
+  error "patternlength=%lu must be >= %lu=prefixlen" (exactcompl.c:179-185):
+  the matches of the queries before it are delivered, the return code is
+  negative.  In every match length = query length and querystart = 0.
+*/
+int vsa_findcompletematches(const vsa_index *index,
+                            const vsa_queries *queries, vsa_result **result);
+
+/*
+  findquerymatches (Vmengine/fquery.c:1009-1058) for exact matches:
+    domaximaluniquematch = 0                      vmatch -l L        (MEM)
+    domaximaluniquematch = 1, ...candidates = 1   vmatch -mum cand -l L
+    domaximaluniquematch = 1, ...candidates = 0   vmatch -mum -l L
+  searchlength is Matchparam.seedlength (Vmatch/matchlenparm.c:17-22); a
+  value below prefixlength is the reference's error (fquery.c:440-446).
+  Order: MEM and candidates by query, query offset, then witness / left /
+  right like kurtz/matchsub.c:165-235 with Vmengine/fquery.c:139-270 (the
+  order of vmatch -qspeedup 0); MUMs by ascending dbstart
+  (kurtz/cleanMUMcand.c:55-118).
+*/
+int vsa_findquerymatches(const vsa_index *index, const vsa_queries *queries,
+                         int domaximaluniquematch,
+                         int domaximaluniquematchcandidates,
+                         uint64_t searchlength, vsa_result **result);
+
+/*
+  findmaximaluniquematches (Vmengine/fmumself.c:10-66): MUMs between the
+  database and the query part of one index.  Reported like the reference's
+  Outputfunction(outinfo, len, start1, start2): length, dbstart = start1,
+  queryseq = start2 (absolute), querystart = 0; suffix array order.
+*/
+int vsa_findmaximaluniquematches(const vsa_index *index,
+                                 uint64_t searchlength, vsa_result **result);
+
+/*
+  The same three entry points with the reference's delivery model: every
+  match is handed to a callback on the calling thread, in reference order;
+  a non-zero return stops the run and is propagated
+  (Processfinalfunction, include/match.h:232; procexqu.c:61).
+*/
+typedef int (*vsa_processmatch)(void *info, const vsa_match *match);
+
+int vsa_findcompletematches_cb(const vsa_index *index,
+                               const vsa_queries *queries,
+                               vsa_processmatch processmatch, void *info);
+int vsa_findquerymatches_cb(const vsa_index *index,
+                            const vsa_queries *queries,
+                            int domaximaluniquematch,
+                            int domaximaluniquematchcandidates,
+                            uint64_t searchlength,
+                            vsa_processmatch processmatch, void *info);
+int vsa_findmaximaluniquematches_cb(const vsa_index *index,
+                                    uint64_t searchlength,
+                                    vsa_processmatch processmatch,
+                                    void *info);
+
+/* ---- synthetic inputs (bench.py, tests): SURVEY.md section 8d ---------- */
+
+uint64_t vsa_splitmix64_at(uint64_t seed, uint64_t idx);
+void vsa_synth_genome(uint64_t seed, uint64_t n, uint8_t *codes);
+void vsa_synth_query_plan(uint64_t seed, uint64_t n, uint64_t nq, uint32_t m,
+                          uint64_t *pos, uint32_t *substidx, uint8_t *step);
+void vsa_synth_queries(uint64_t seed, const uint8_t *genome, uint64_t n,
+                       uint64_t nq, uint32_t m, uint8_t *queries,
+                       uint64_t *srcpos);
+/* device-side generators writing into caller-provided device memory */
+int vsa_synth_genome_device(uint64_t seed, uint64_t n, void *device_codes,
+                            int device);
+int vsa_synth_queries_device(const void *device_genome, uint64_t n,
+                             const uint64_t *pos, const uint32_t *substidx,
+                             const uint8_t *step, uint64_t nq, uint32_t m,
+                             void *device_queries, int device);
+
+/* plain device memory for callers without a HIP runtime of their own */
+int vsa_device_malloc(uint64_t bytes, int device, void **ptr);
+int vsa_device_free(void *ptr, int device);
+int vsa_device_count(void);
+/* measured device-to-device streaming read rate in GB/s (roofline
+   denominator cross-check in bench.py) */
+int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
