@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container (needs /root/reference and the programs built by
+`make -f oracle/Makefile.ref`):
+
+    python3 scripts/make_golden.py
+
+For every case it runs oracle/_ref/mkvtree_ref and oracle/_ref/vmatch_ref and
+stores DATA only:
+  * the input sequences (small FASTA files taken from the reference's own
+    test data src/testdata/Grumbach, src/Vmatch/Testdir, or produced by the
+    deterministic generator of vstree_amd/csrc/synth.c),
+  * md5 sums of the index tables mkvtree wrote and the .prj numbers,
+  * the match lists vmatch printed, parsed into integer arrays
+    (length, dbseq, dbrel, queryseq, querystart) in output order.
+The reference's known-answer file src/Vmatch/Testdir/LargePat.res is stored
+as it is (it is a data fixture of the reference's own test suite,
+src/Vmatch/Itercomplete.sh:25-33).
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import helpers as H  # noqa: E402
+import vstree_amd as V  # noqa: E402
+
+REFSRC = "/root/reference/src"
+GOLD = os.path.join(ROOT, "tests", "golden")
+TABLES = ("tis", "suf", "lcp", "llv", "bck", "bwt", "sti1")
+
+
+def md5file(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+def gzcopy(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
+        g.write(f.read())
+
+
+def index_case(wd, indexname, mkvargs):
+    H.run_mkvtree_ref(mkvargs, wd)
+    prefix = os.path.join(wd, indexname)
+    prj = H.read_prj(prefix + ".prj")
+    return {"prj": {k: v for k, v in prj.items()
+                    if k not in ("dbfile", "queryfile")},
+            "md5": {t: md5file(prefix + "." + t) for t in TABLES}}
+
+
+def run_case(wd, args):
+    rc, lines, err = H.run_vmatch_ref(args, wd)
+    return rc, lines, err
+
+
+def main():
+    if not H.have_ref():
+        sys.exit("build the reference first: make -f oracle/Makefile.ref")
+    os.makedirs(GOLD, exist_ok=True)
+    manifest, arrays = {}, {}
+
+    def record(case, key, args, wd, selfmatch=False):
+        rc, lines, err = run_case(wd, args)
+        entry = {"args": args, "rc": rc, "lines": len(lines),
+                 "md5_lines": hashlib.md5(
+                     ("\n".join(lines) + "\n").encode()).hexdigest()}
+        arrays["%s__%s" % (case, key)] = H.parse_vmatch_lines(lines)
+        if rc != 0:
+            entry["stderr"] = err.strip()
+        manifest[case]["runs"][key] = entry
+
+    # ---- 1. LargePat: the reference's own known-answer test --------------
+    wd = tempfile.mkdtemp()
+    case = "largepat"
+    shutil.copy(REFSRC + "/testdata/Grumbach/ychrIII.fna", wd)
+    shutil.copy(REFSRC + "/Vmatch/Testdir/LargePat.test", wd)
+    gzcopy(wd + "/ychrIII.fna", GOLD + "/ychrIII.fna.gz")
+    shutil.copy(wd + "/LargePat.test", GOLD + "/LargePat.test")
+    shutil.copy(REFSRC + "/Vmatch/Testdir/LargePat.res",
+                GOLD + "/LargePat.res")
+    manifest[case] = {"db": ["ychrIII.fna.gz"], "query": "LargePat.test",
+                      "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "ychrIII.fna", ["-db", "ychrIII.fna", "-dna", "-pl", "-allout"])
+    record(case, "complete", ["-complete", "-d", "-q", "LargePat.test",
+                              "ychrIII.fna"], wd)
+    for sp in (0, 2):
+        record(case, "mem20_sp%d" % sp,
+               ["-qspeedup", str(sp), "-l", "20", "-q", "LargePat.test",
+                "ychrIII.fna"], wd)
+    record(case, "mem300", ["-l", "300", "-q", "LargePat.test",
+                            "ychrIII.fna"], wd)
+    shutil.rmtree(wd)
+
+    # ---- 2. micro: multi-FASTA, wildcards, prefixlength 1 ----------------
+    wd = tempfile.mkdtemp()
+    case = "micro"
+    db = [("s0", b"acgtacgtttgacnnacgtacgtaaccggtt"),
+          ("s1", b"ttgacgacgtacgtttga"), ("s2", b"ggggacgtacgt")]
+    qs = [("q0", b"acgtacgt"), ("q1", b"acgnacgt"), ("q2", b"gacnnacg"),
+          ("q3", b"gtcaa"), ("q4", b"tacgt"), ("q5", b"ttgacgacgtacgtttgat"),
+          ("q6", b"nnnnn"), ("q7", b"ggggacgtacgtn")]
+    H.write_fasta(wd + "/db.fna", db)
+    H.write_fasta(wd + "/q.fna", qs)
+    H.write_fasta(wd + "/qshort.fna", qs[:2] + [("tiny", b"")] + qs[2:])
+    for f in ("db.fna", "q.fna"):
+        shutil.copy(wd + "/" + f, GOLD + "/micro_" + f)
+    manifest[case] = {"db": ["micro_db.fna"], "query": "micro_q.fna",
+                      "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "db.fna", ["-db", "db.fna", "-dna", "-pl", "-allout"])
+    record(case, "complete", ["-complete", "-q", "q.fna", "db.fna"], wd)
+    for L in (1, 3, 5):
+        for sp in (0, 2):
+            record(case, "mem%d_sp%d" % (L, sp),
+                   ["-qspeedup", str(sp), "-l", str(L), "-q", "q.fna",
+                    "db.fna"], wd)
+        record(case, "mumcand%d" % L, ["-mum", "cand", "-l", str(L), "-q",
+                                       "q.fna", "db.fna"], wd)
+        record(case, "mum%d" % L, ["-mum", "-l", str(L), "-q", "q.fna",
+                                   "db.fna"], wd)
+    shutil.rmtree(wd)
+
+    # ---- 3. Wildcards.fna of the reference's test data --------------------
+    wd = tempfile.mkdtemp()
+    case = "wildcards"
+    shutil.copy(REFSRC + "/testdata/Grumbach/Wildcards.fna", wd)
+    shutil.copy(wd + "/Wildcards.fna", GOLD + "/Wildcards.fna")
+    manifest[case] = {"db": ["Wildcards.fna"], "query": "Wildcards.fna",
+                      "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "Wildcards.fna", ["-db", "Wildcards.fna", "-dna", "-pl",
+                              "-allout"])
+    record(case, "mem2", ["-l", "2", "-q", "Wildcards.fna",
+                          "Wildcards.fna"], wd)
+    record(case, "mumcand2", ["-mum", "cand", "-l", "2", "-q",
+                              "Wildcards.fna", "Wildcards.fna"], wd)
+    shutil.rmtree(wd)
+
+    # ---- 4. a Grumbach pair, as in src/Vmatch/Mum.sh / Itermum.sh ---------
+    wd = tempfile.mkdtemp()
+    case = "grumbach"
+    dbf, qf = "humhbb.fna", "humdystrop.fna"
+    for f in (dbf, qf):
+        shutil.copy(REFSRC + "/testdata/Grumbach/" + f, wd)
+        gzcopy(wd + "/" + f, GOLD + "/" + f + ".gz")
+    manifest[case] = {"db": [dbf + ".gz"], "query": qf + ".gz", "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, dbf, ["-db", dbf, "-dna", "-pl", "-allout"])
+    for sp in (0, 2):
+        record(case, "mem14_sp%d" % sp, ["-qspeedup", str(sp), "-l", "14",
+                                         "-q", qf, dbf], wd)
+    record(case, "mumcand14", ["-mum", "cand", "-l", "14", "-q", qf, dbf], wd)
+    record(case, "mum14", ["-mum", "-l", "14", "-q", qf, dbf], wd)
+    # queries shorter than prefixlength (6 here): a hard error for -complete
+    # after the matches of the queries in front of it (exactcompl.c:179-185),
+    # silently skipped for -l (matchsub.c:187-190)
+    H.write_fasta(wd + "/short.fna",
+                  [("a", b"ttttcaacctctttgt"), ("b", b"agacaccatggtgcacctg"),
+                   ("c", b"acgta"), ("d", b"gtgcacctgactcctgag")])
+    shutil.copy(wd + "/short.fna", GOLD + "/short.fna")
+    record(case, "complete_short", ["-complete", "-q", "short.fna", dbf], wd)
+    record(case, "mem8_short", ["-l", "8", "-q", "short.fna", dbf], wd)
+    # queries inside the index (Mum.sh:35-61): vmatch -mum on db+query index
+    manifest["grumbach_all"] = {"db": [dbf + ".gz"], "indexedquery":
+                                [qf + ".gz"], "runs": {}}
+    manifest["grumbach_all"]["index"] = index_case(
+        wd, "all", ["-indexname", "all", "-db", dbf, "-q", qf, "-dna", "-pl",
+                    "-allout"])
+    record("grumbach_all", "selfmum14", ["-mum", "-l", "14", "all"], wd)
+    shutil.rmtree(wd)
+
+    # ---- 5. C1: synthetic 1 Mbp genome, 10 k x 100 bp queries -------------
+    wd = tempfile.mkdtemp()
+    case = "c1"
+    n, nq, m = 1000000, 10000, 100
+    g = V.synth_genome(n)
+    qb = V.synth_queries(g, nq, m)
+    H.write_fasta(wd + "/genome.fna", [("synthetic_genome seed=42", g)])
+    H.write_fasta(wd + "/queries.fna",
+                  [("q%d" % i, qb[i * m:(i + 1) * m]) for i in range(nq)],
+                  width=1000)
+    manifest[case] = {"synthetic": {"n": n, "nq": nq, "m": m,
+                                    "genome_seed": 42, "query_seed": 4242},
+                      "md5_genome_fna": md5file(wd + "/genome.fna"),
+                      "md5_queries_fna": md5file(wd + "/queries.fna"),
+                      "md5_genome_codes": hashlib.md5(g.tobytes()).hexdigest(),
+                      "md5_query_codes": hashlib.md5(qb.tobytes()).hexdigest(),
+                      "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "genome.fna", ["-db", "genome.fna", "-dna", "-pl", "-allout"])
+    record(case, "complete", ["-complete", "-q", "queries.fna",
+                              "genome.fna"], wd)
+    for sp in (0, 2):
+        record(case, "mem20_sp%d" % sp, ["-qspeedup", str(sp), "-l", "20",
+                                         "-q", "queries.fna", "genome.fna"],
+               wd)
+    record(case, "mumcand20", ["-mum", "cand", "-l", "20", "-q",
+                               "queries.fna", "genome.fna"], wd)
+    record(case, "mum20", ["-mum", "-l", "20", "-q", "queries.fna",
+                           "genome.fna"], wd)
+    shutil.rmtree(wd)
+
+    np.savez_compressed(GOLD + "/expected.npz", **arrays)
+    with open(GOLD + "/manifest.json", "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote", len(arrays), "match lists for", len(manifest), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -472,3 +472,116 @@ def matches_as_ref(index, m):
 
 def sorted_matches(m):
     return np.sort(m, order=list(m.dtype.names))
+
+
+# --------------------------------------------------------------------------
+# golden cases (tests/golden, written by scripts/make_golden.py)
+# --------------------------------------------------------------------------
+
+import gzip as _gzip
+import hashlib as _hashlib
+import json as _json
+import tempfile as _tempfile
+
+_manifest = None
+_expected = None
+_cases = {}
+
+
+def manifest():
+    global _manifest
+    if _manifest is None:
+        with open(os.path.join(GOLDEN, "manifest.json")) as f:
+            _manifest = _json.load(f)
+    return _manifest
+
+
+def expected(case, key):
+    global _expected
+    if _expected is None:
+        _expected = np.load(os.path.join(GOLDEN, "expected.npz"))
+    return _expected["%s__%s" % (case, key)]
+
+
+def _golden_fasta(name):
+    """path of a (possibly gzipped) golden FASTA, unpacked to a temp file"""
+    p = os.path.join(GOLDEN, name)
+    if not name.endswith(".gz"):
+        return p
+    out = os.path.join(_tempfile.gettempdir(),
+                       "vsa_golden_%d_%s" % (os.getuid(), name[:-3]))
+    if not os.path.exists(out):
+        with _gzip.open(p, "rb") as f, open(out + ".tmp", "wb") as g:
+            g.write(f.read())
+        os.replace(out + ".tmp", out)
+    return out
+
+
+def synth_c1():
+    """(genome codes, query codes, n, nq, m) of golden case c1"""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import vstree_amd as V
+    s = manifest()["c1"]["synthetic"]
+    g = V.synth_genome(s["n"], s["genome_seed"])
+    q = V.synth_queries(g, s["nq"], s["m"], s["query_seed"])
+    return g, q, s["n"], s["nq"], s["m"]
+
+
+def table_md5(index):
+    """md5 of the tables in the reference's 64-bit on-disk layout"""
+    i64 = index.as_width(64)
+    return {"tis": _hashlib.md5(i64.tis.tobytes()).hexdigest(),
+            "suf": _hashlib.md5(i64.suf.tobytes()).hexdigest(),
+            "lcp": _hashlib.md5(i64.lcp.tobytes()).hexdigest(),
+            "llv": _hashlib.md5(i64.llv.tobytes()).hexdigest(),
+            "bck": _hashlib.md5(i64.bck.tobytes()).hexdigest(),
+            "bwt": _hashlib.md5(i64.bwt.tobytes()).hexdigest(),
+            "sti1": _hashlib.md5(i64.sti1.tobytes()).hexdigest()}
+
+
+def load_case(case):
+    """-> (Index built by the CPU oracle builder, Queries or None).
+    The tables are checked against the md5 sums of what the reference's
+    mkvtree wrote, so every user of a case starts from reference tables."""
+    if case in _cases:
+        return _cases[case]
+    m = manifest()[case]
+    pl = m["index"]["prj"]["prefixlength"]
+    queries = None
+    if "synthetic" in m:
+        g, qb, n, nq, mm = synth_c1()
+        idx = oracle_build_index(g, 4, pl)
+        queries = Queries.uniform(qb, mm)
+    else:
+        files = [_golden_fasta(f) for f in m["db"]]
+        qfiles = [_golden_fasta(f) for f in m.get("indexedquery", [])]
+        tis, ssp, perfile = fasta_text(files + qfiles)
+        hasq = bool(qfiles)
+        qsep = int(ssp[sum(perfile[:len(files)]) - 1]) if hasq else 0
+        idx = oracle_build_index(tis, 4, pl, ssp=ssp, querysepposition=qsep,
+                                 hasqueries=hasq)
+        idx.numofdbsequences = sum(perfile[:len(files)])
+        if "query" in m:
+            queries = fasta_queries(_golden_fasta(m["query"]))
+    got = table_md5(idx)
+    assert got == m["index"]["md5"], (case, got, m["index"]["md5"])
+    if not hasattr(idx, "numofdbsequences"):
+        idx.numofdbsequences = idx.numofsequences
+    _cases[case] = (idx, queries)
+    return _cases[case]
+
+
+def selfmatches_as_ref(index, m):
+    """self-MUM records (length, start1, start2) -> the reference's output
+    tuple; the second sequence number counts from the first query sequence"""
+    dt = np.dtype([("length", "<u8"), ("dbseq", "<u8"), ("dbrel", "<u8"),
+                   ("queryseq", "<u8"), ("querystart", "<u8")])
+    out = np.zeros(m.shape[0], dt)
+    s1, r1 = index.seq_rel(m["dbstart"])
+    s2, r2 = index.seq_rel(m["queryseq"])
+    out["length"], out["dbseq"], out["dbrel"] = m["length"], s1, r1
+    out["queryseq"] = s2 - np.uint64(index.numofdbsequences)
+    out["querystart"] = r2
+    return out

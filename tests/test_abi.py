@@ -1,0 +1,83 @@
+"""CPU-side checks of the product library: it loads without a GPU, exports
+every symbol include/vstree_amd.h declares, its host-only entry points
+(synthetic generator, index reader errors) behave, and nothing in the product
+tree touches the oracle."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def header_symbols():
+    text = open(os.path.join(H.ROOT, "include", "vstree_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vsa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(V):
+    syms = header_symbols()
+    assert len(syms) >= 30
+    lib = C.CDLL(V.LIBPATH)
+    for s in syms:
+        assert hasattr(lib, s), "missing export %s" % s
+    # and the Python binding covers the same set
+    assert sorted(V.ABI_SYMBOLS) == syms
+
+
+def test_synthetic_generator_matches_recorded_md5(V):
+    m = H.manifest()["c1"]
+    g, q, n, nq, mm = H.synth_c1()
+    assert hashlib.md5(g.tobytes()).hexdigest() == m["md5_genome_codes"]
+    assert hashlib.md5(q.tobytes()).hexdigest() == m["md5_query_codes"]
+    # the plan materialises the same queries
+    pos, sub, step = V.synth_query_plan(n, nq, mm)
+    q2 = np.stack([g[int(p):int(p) + mm] for p in pos]).copy()
+    for i in np.nonzero(sub != V.NO_SUBST)[0]:
+        q2[i, sub[i]] = (q2[i, sub[i]] + step[i]) % 4
+    assert np.array_equal(q2.ravel(), q)
+    # splitmix64 is addressable by index
+    assert (V.lib.vsa_splitmix64_at(42, 0) >> 62) == g[0]
+    assert (V.lib.vsa_splitmix64_at(42, 999) >> 62) == g[999]
+
+
+def test_index_open_reports_reference_style_errors(V, tmp_path):
+    with pytest.raises(V.VsaError) as e:
+        V.Index.open(str(tmp_path / "nothing"))
+    assert "cannot open" in e.value.message
+    # a .prj with an integer size that is neither 32 nor 64
+    p = tmp_path / "bad"
+    (tmp_path / "bad.prj").write_text(
+        "totallength=10\nprefixlength=1\nlargelcpvalues=0\n"
+        "integersize=16\nlittleendian=1\n")
+    (tmp_path / "bad.al1").write_text("aA\ncC\ngG\ntTuU\nnN\n")
+    with pytest.raises(V.VsaError) as e:
+        V.Index.open(str(p))
+    assert "integer size" in e.value.message
+    # table of the wrong size (the reference's EXPECTED check)
+    (tmp_path / "bad.prj").write_text(
+        "totallength=10\nprefixlength=1\nlargelcpvalues=0\n"
+        "integersize=64\nlittleendian=1\n")
+    (tmp_path / "bad.tis").write_bytes(b"\0" * 9)
+    with pytest.raises(V.VsaError) as e:
+        V.Index.open(str(p))
+    assert "expected 10" in e.value.message
+
+
+def test_product_tree_never_touches_the_oracle():
+    bad = []
+    for base in ("vstree_amd", "include"):
+        for dp, dn, fn in os.walk(os.path.join(H.ROOT, base)):
+            if "_build" in dp or "__pycache__" in dp:
+                continue
+            for f in fn:
+                if f.endswith((".so", ".o", ".pyc")):
+                    continue
+                text = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"liboracle|vsoracle|orc_[a-z]+\(|oracle/", text):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

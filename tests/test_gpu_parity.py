@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+golden outputs of the real reference.  Bit-exact, order included."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+M = H.manifest()
+
+_gpu_index = {}
+
+
+def gpu_index(V, case, bits=64):
+    key = (case, bits)
+    if key not in _gpu_index:
+        idx, _ = H.load_case(case)
+        i = idx.as_width(bits)
+        _gpu_index[key] = V.Index.from_tables(
+            i.n, i.prefixlength, i.numofchars, i.tis, i.suf, i.lcp, i.llv,
+            i.bck, i.bwt, i.querysepposition, i.hasqueries)
+    return _gpu_index[key]
+
+
+def gpu_queries(V, q):
+    return V.Queries.from_host(q.symbols, q.start, q.length)
+
+
+def run_gpu(V, case, key, bits=64):
+    idx, q = H.load_case(case)
+    gi = gpu_index(V, case, bits)
+    if key.startswith("selfmum"):
+        r = V.findmaximaluniquematches(gi, int(key[len("selfmum"):]))
+        return H.selfmatches_as_ref(idx, r.fetch())
+    gq = gpu_queries(V, q)
+    if key.startswith("complete"):
+        return H.matches_as_ref(idx, V.findcompletematches(gi, gq).fetch())
+    name = key.partition("_sp")[0]
+    if name.startswith("mumcand"):
+        L, kw = int(name[7:]), dict(mum=True, cand=True)
+    elif name.startswith("mum"):
+        L, kw = int(name[3:]), dict(mum=True)
+    else:
+        L, kw = int(name[3:].split("_")[0]), {}
+    return H.matches_as_ref(idx, V.findquerymatches(gi, gq, L, **kw).fetch())
+
+
+# MEM order on the GPU is the order of vmatch -qspeedup 0 (algorithm 0); the
+# default algorithm 2 reports the same set, possibly in another order inside
+# one query offset -- so _sp2 lists are compared as sets, all others in order
+CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
+         if not k.endswith("_short")]
+
+
+@pytest.mark.parametrize("case,key", CASES)
+def test_gpu_reproduces_reference_output(V, case, key):
+    got = run_gpu(V, case, key)
+    want = H.expected(case, key)
+    assert len(got) == len(want)
+    if key.endswith("_sp2"):
+        assert np.array_equal(H.sorted_matches(got), H.sorted_matches(want))
+    else:
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["micro", "grumbach", "largepat"])
+def test_gpu_equals_oracle_32bit_tables(V, case):
+    idx, q = H.load_case(case)
+    gi = gpu_index(V, case, 32)
+    gq = gpu_queries(V, q)
+    pl = idx.prefixlength
+    assert np.array_equal(V.findcompletematches(gi, gq).fetch()
+                          if q.length.min() >= pl else np.zeros(0),
+                          H.oracle_complete(idx, q)
+                          if q.length.min() >= pl else np.zeros(0))
+    L = max(pl, 8 if case != "micro" else 2)
+    for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
+        a = V.findquerymatches(gi, gq, L, **kw).fetch()
+        b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
+        assert np.array_equal(a, b), (case, kw)
+
+
+def test_largepat_known_answer_file_gpu(V):
+    idx, q = H.load_case("largepat")
+    got = run_gpu(V, "largepat", "complete")
+    with open(os.path.join(H.GOLDEN, "LargePat.res")) as f:
+        want = H.parse_vmatch_lines([l for l in f.read().splitlines() if l])
+    assert np.array_equal(got, want)
+
+
+def test_short_query_is_the_references_hard_error(V):
+    idx, _ = H.load_case("grumbach")
+    q = H.fasta_queries(os.path.join(H.GOLDEN, "short.fna"))
+    gi, gq = gpu_index(V, "grumbach"), gpu_queries(V, q)
+    with pytest.raises(V.VsaError) as e:
+        V.findcompletematches(gi, gq)
+    assert e.value.message == "patternlength=5 must be >= 6=prefixlen"
+    got = H.matches_as_ref(idx, e.value.partial.fetch())
+    assert np.array_equal(got, H.expected("grumbach", "complete_short"))
+    # -l skips the short query silently
+    got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 8).fetch())
+    assert np.array_equal(H.sorted_matches(got),
+                          H.sorted_matches(H.expected("grumbach",
+                                                      "mem8_short")))
+    # searchlength below prefixlength: fquery.c:440-446
+    with pytest.raises(V.VsaError) as e:
+        V.findquerymatches(gi, gq, 5)
+    assert e.value.message == "searchlength=5 must be >= 6=prefixlen"
+
+
+def test_empty_and_degenerate_batches(V):
+    idx, q = H.load_case("micro")
+    gi = gpu_index(V, "micro")
+    empty = V.Queries.from_host(np.zeros(0, np.uint8), np.zeros(0, np.uint64),
+                                np.zeros(0, np.uint64))
+    assert V.findcompletematches(gi, empty).count == 0
+    assert V.findquerymatches(gi, empty, 3).count == 0
+    # queries that are all wildcards / shorter than the search length
+    qq = H.Queries.from_list([[254, 254, 254], [0, 1], [3]])
+    gq = gpu_queries(V, qq)
+    assert V.findquerymatches(gi, gq, 3).count == 0
+    assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
+                          H.oracle_complete(idx, qq))
+
+
+def test_callback_delivery_order_and_stop(V):
+    idx, q = H.load_case("grumbach")
+    gi, gq = gpu_index(V, "grumbach"), gpu_queries(V, q)
+    want = H.oracle_querymatches(idx, q, 14, speedup=0)
+    rc, got = V.findquerymatches_cb(gi, gq, 14)
+    assert rc == 0
+    assert got == [tuple(int(x) for x in r) for r in want.tolist()]
+    # a non-zero return of the callback stops the run (procexqu.c:61-64)
+    rc, got = V.findquerymatches_cb(gi, gq, 14, stop_after=5)
+    assert rc != 0 and len(got) == 5
+    rc, got = V.findcompletematches_cb(gi, gpu_queries(
+        V, H.fasta_queries(os.path.join(H.GOLDEN, "short.fna"))))
+    assert rc < 0 and len(got) == 1       # one match, then the hard error
+    allidx, _ = H.load_case("grumbach_all")
+    rc, got = V.findmaximaluniquematches_cb(gpu_index(V, "grumbach_all"), 14)
+    assert rc == 0
+    assert got == [tuple(int(x) for x in r)
+                   for r in H.oracle_selfmum(allidx, 14).tolist()]
+
+
+def test_index_open_reads_mkvtree_files(V, tmp_path):
+    """the C reader (vsa_index_open) on files in the reference's layout"""
+    idx, q = H.load_case("grumbach_all")
+    prefix = str(tmp_path / "all")
+    i64 = idx.as_width(64)
+    for sfx, arr in (("tis", i64.tis), ("suf", i64.suf), ("lcp", i64.lcp),
+                     ("llv", i64.llv), ("bck", i64.bck), ("bwt", i64.bwt),
+                     ("ssp", i64.ssp.astype(np.uint64))):
+        arr.tofile(prefix + "." + sfx)
+    prj = M["grumbach_all"]["index"]["prj"]
+    with open(prefix + ".prj", "w") as f:
+        f.write("dbfile=humhbb.fna 74522 73308\n")
+        f.write("queryfile=humdystrop.fna 39422 38770\n")
+        for k in ("totallength", "specialcharacters", "specialranges",
+                  "lengthofspecialprefix", "lengthofspecialsuffix",
+                  "numofsequences", "numofdbsequences",
+                  "numofquerysequences", "longest", "prefixlength",
+                  "largelcpvalues", "maxbranchdepth", "integersize",
+                  "littleendian"):
+            f.write("%s=%d\n" % (k, prj[k]))
+    with open(prefix + ".al1", "w") as f:
+        f.write("aA\ncC\ngG\ntTuU\nnsywrkvbdhmNSYWRKVBDHM\n")
+    gi = V.Index.open(prefix)
+    info = gi.info()
+    assert info.totallength == idx.n and info.prefixlength == 6
+    assert info.hasindexedqueries == 1 and info.device_integersize == 32
+    got = H.selfmatches_as_ref(idx, V.findmaximaluniquematches(gi, 14).fetch())
+    assert np.array_equal(got, H.expected("grumbach_all", "selfmum14"))
+
+
+def test_random_ragged_queries_with_wildcards(V):
+    """seeded random index with separators and wildcards, ragged queries"""
+    rng = np.random.default_rng(777)
+    parts = []
+    for i in range(5):
+        s = rng.integers(0, 4, size=int(rng.integers(3000, 9000))).astype(
+            np.uint8)
+        s[rng.integers(0, len(s), size=4)] = H.WILDCARD
+        parts.append(s)
+        parts.append(np.array([H.SEPARATOR], np.uint8))
+    tis = np.concatenate(parts[:-1])
+    idx = H.oracle_build_index(tis, 4)
+    gi = V.Index.from_tables(idx.n, idx.prefixlength, 4, idx.tis, idx.suf,
+                             idx.lcp, idx.llv, idx.bck, idx.bwt)
+    seqs = []
+    for i in range(2000):
+        L = int(rng.integers(idx.prefixlength, 200))
+        p = int(rng.integers(0, idx.n - L))
+        s = tis[p:p + L].copy()
+        if rng.random() < 0.4:
+            s[int(rng.integers(0, L))] = int(rng.integers(0, 4))
+        seqs.append(s)
+    q = H.Queries.from_list(seqs)
+    gq = gpu_queries(V, q)
+    assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
+                          H.oracle_complete(idx, q))
+    L = idx.prefixlength + 3
+    for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
+        assert np.array_equal(V.findquerymatches(gi, gq, L, **kw).fetch(),
+                              H.oracle_querymatches(idx, q, L, speedup=0,
+                                                    **kw)), kw
+
+
+def test_repeats_beyond_255_and_many_occurrences(V):
+    """long runs: lcp values >= 255 (llv exceptions) and thousands of hits"""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, size=400).astype(np.uint8)
+    tis = np.concatenate([unit, unit, rng.integers(0, 4, 500).astype(np.uint8),
+                          unit, np.zeros(3000, np.uint8),
+                          rng.integers(0, 4, 2000).astype(np.uint8)])
+    idx = H.oracle_build_index(tis, 4, 4)
+    assert idx.nllv > 0
+    gi = V.Index.from_tables(idx.n, idx.prefixlength, 4, idx.tis, idx.suf,
+                             idx.lcp, idx.llv, idx.bck, idx.bwt)
+    q = H.Queries.from_list([unit, unit[:300], unit[50:350],
+                             np.zeros(20, np.uint8), np.zeros(300, np.uint8),
+                             np.concatenate([unit[100:], unit[:100]])])
+    gq = gpu_queries(V, q)
+    assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
+                          H.oracle_complete(idx, q))
+    for L in (8, 260):
+        for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
+            a = V.findquerymatches(gi, gq, L, **kw).fetch()
+            b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
+            assert np.array_equal(a, b), (L, kw)

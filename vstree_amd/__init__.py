@@ -1,0 +1,385 @@
+"""vstree_amd -- ctypes binding of the MI355X-native Vmengine query path.
+
+The product is the C-ABI library vstree_amd/libvstree_amd.so (HIP kernels for
+gfx950 + C host code; ABI in include/vstree_amd.h).  This module only maps it
+into Python for the tests and bench.py, keeping the reference's operator names
+(findcompletematches / findquerymatches / findmaximaluniquematches of
+/root/reference/src/Vmengine/vmengineexport.h:4-81).
+
+There is no CPU fallback: if the library is missing, importing fails; if no
+GPU is present, every compute call returns the HIP error.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, "libvstree_amd.so")
+
+SEPARATOR = 255
+WILDCARD = 254
+NO_SUBST = 0xFFFFFFFF
+
+MATCH_DTYPE = np.dtype([("length", "<u8"), ("dbstart", "<u8"),
+                        ("queryseq", "<u8"), ("querystart", "<u8")])
+
+
+class VsaError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("vstree_amd error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+class Tables(C.Structure):
+    _fields_ = [("totallength", C.c_uint64), ("prefixlength", C.c_uint32),
+                ("numofchars", C.c_uint32), ("integersize", C.c_uint32),
+                ("largelcpvalues", C.c_uint64), ("tis", C.c_void_p),
+                ("suf", C.c_void_p), ("lcp", C.c_void_p),
+                ("llv", C.c_void_p), ("bck", C.c_void_p),
+                ("bwt", C.c_void_p), ("querysepposition", C.c_uint64),
+                ("hasindexedqueries", C.c_int)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("totallength", C.c_uint64), ("numofcodes", C.c_uint64),
+                ("largelcpvalues", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("prefixlength", C.c_uint32), ("numofchars", C.c_uint32),
+                ("device_integersize", C.c_uint32), ("device", C.c_int),
+                ("hasindexedqueries", C.c_int), ("hasbwt", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("sumlength", C.c_uint64),
+                ("searches", C.c_uint64), ("candidates", C.c_uint64),
+                ("search_kernel_ms", C.c_double),
+                ("total_device_ms", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+PROCESSMATCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+def _load():
+    if not os.path.exists(LIBPATH):
+        raise ImportError(
+            "%s is missing: build it with `make -C vstree_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback"
+            % LIBPATH)
+    lib = C.CDLL(LIBPATH)
+    V, U64, U32, I = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    PP = C.POINTER(C.c_void_p)
+    sig = {
+        "vsa_messagespace": (C.c_char_p, []),
+        "vsa_index_from_tables": (I, [C.POINTER(Tables), I, PP]),
+        "vsa_index_open": (I, [C.c_char_p, I, PP]),
+        "vsa_index_close": (None, [V]),
+        "vsa_index_getinfo": (I, [V, C.POINTER(IndexInfo)]),
+        "vsa_index_build": (I, [V, U64, U32, U32, I, PP]),
+        "vsa_index_build_device": (I, [V, U64, U32, U32, I, PP]),
+        "vsa_index_download": (I, [V, V, V, V, V, V, V]),
+        "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
+        "vsa_queries_from_device": (I, [V, U64, U32, I, PP]),
+        "vsa_queries_free": (None, [V]),
+        "vsa_result_count": (U64, [V]),
+        "vsa_result_getstats": (I, [V, C.POINTER(Stats)]),
+        "vsa_result_fetch": (I, [V, V, U64]),
+        "vsa_result_device_matches": (V, [V]),
+        "vsa_result_free": (None, [V]),
+        "vsa_findcompletematches": (I, [V, V, PP]),
+        "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
+        "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
+        "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
+        "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
+        "vsa_findmaximaluniquematches_cb": (I, [V, U64, PROCESSMATCH, V]),
+        "vsa_splitmix64_at": (U64, [U64, U64]),
+        "vsa_synth_genome": (None, [U64, U64, V]),
+        "vsa_synth_query_plan": (None, [U64, U64, U64, U32, V, V, V]),
+        "vsa_synth_queries": (None, [U64, V, U64, U64, U32, V, V]),
+        "vsa_synth_genome_device": (I, [U64, U64, V, I]),
+        "vsa_synth_queries_device": (I, [V, U64, V, V, V, U64, U32, V, I]),
+        "vsa_device_malloc": (I, [U64, I, PP]),
+        "vsa_device_free": (I, [V, I]),
+        "vsa_device_count": (I, []),
+        "vsa_measure_stream_read": (I, [U64, I, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib, sorted(sig)
+
+
+lib, ABI_SYMBOLS = _load()
+
+
+def messagespace():
+    return lib.vsa_messagespace().decode(errors="replace")
+
+
+def _check(rc):
+    if rc != 0:
+        raise VsaError(rc, messagespace())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Index:
+    """An enhanced suffix array resident in one GPU's HBM (vsa_index)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_tables(cls, totallength, prefixlength, numofchars, tis, suf, lcp,
+                    llv, bck, bwt=None, querysepposition=0,
+                    hasindexedqueries=False, device=0):
+        suf = np.ascontiguousarray(suf)
+        assert suf.dtype in (np.uint32, np.uint64)
+        tis = np.ascontiguousarray(tis, np.uint8)
+        lcp = np.ascontiguousarray(lcp, np.uint8)
+        llv = np.ascontiguousarray(llv, suf.dtype)
+        bck = np.ascontiguousarray(bck, suf.dtype)
+        bwt = None if bwt is None else np.ascontiguousarray(bwt, np.uint8)
+        t = Tables(int(totallength), int(prefixlength), int(numofchars),
+                   suf.dtype.itemsize * 8, llv.shape[0] // 2, _ptr(tis),
+                   _ptr(suf), _ptr(lcp), _ptr(llv), _ptr(bck), _ptr(bwt),
+                   int(querysepposition), int(bool(hasindexedqueries)))
+        h = C.c_void_p()
+        _check(lib.vsa_index_from_tables(C.byref(t), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def open(cls, indexname, device=0):
+        """mapvirtualtreeifyoucan + upload (vsa_index_open)."""
+        h = C.c_void_p()
+        _check(lib.vsa_index_open(os.fsencode(indexname), device,
+                                  C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build(cls, tis, numofchars=4, prefixlength=0, device=0):
+        tis = np.ascontiguousarray(tis, np.uint8)
+        h = C.c_void_p()
+        _check(lib.vsa_index_build(_ptr(tis), tis.shape[0], numofchars,
+                                   prefixlength, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build_device(cls, device_tis, totallength, numofchars=4,
+                     prefixlength=0, device=0):
+        h = C.c_void_p()
+        _check(lib.vsa_index_build_device(device_tis, totallength, numofchars,
+                                          prefixlength, device, C.byref(h)))
+        return cls(h)
+
+    def info(self):
+        i = IndexInfo()
+        _check(lib.vsa_index_getinfo(self._h, C.byref(i)))
+        return i
+
+    def download(self, with_bwt=True):
+        """-> dict of numpy arrays with the device tables."""
+        i = self.info()
+        dt = np.uint32 if i.device_integersize == 32 else np.uint64
+        n = i.totallength
+        out = {"tis": np.zeros(n, np.uint8), "suf": np.zeros(n + 1, dt),
+               "lcp": np.zeros(n + 1, np.uint8),
+               "llv": np.zeros(2 * i.largelcpvalues, dt),
+               "bck": np.zeros(2 * i.numofcodes, dt),
+               "bwt": (np.zeros(n + 1, np.uint8)
+                       if (with_bwt and i.hasbwt) else None)}
+        _check(lib.vsa_index_download(self._h, _ptr(out["tis"]),
+                                      _ptr(out["suf"]), _ptr(out["lcp"]),
+                                      _ptr(out["llv"]), _ptr(out["bck"]),
+                                      _ptr(out["bwt"])))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.vsa_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Queries:
+    """A batch of query sequences resident in HBM (vsa_queries)."""
+
+    def __init__(self, handle, nq):
+        self._h = handle
+        self.nq = nq
+
+    @classmethod
+    def from_host(cls, symbols, start, length, device=0):
+        symbols = np.ascontiguousarray(symbols, np.uint8)
+        start = np.ascontiguousarray(start, np.uint64)
+        length = np.ascontiguousarray(length, np.uint64)
+        h = C.c_void_p()
+        _check(lib.vsa_queries_from_host(_ptr(symbols), symbols.shape[0],
+                                         _ptr(start), _ptr(length),
+                                         start.shape[0], device, C.byref(h)))
+        return cls(h, start.shape[0])
+
+    @classmethod
+    def from_device(cls, device_symbols, nq, m, device=0):
+        h = C.c_void_p()
+        _check(lib.vsa_queries_from_device(device_symbols, nq, m, device,
+                                           C.byref(h)))
+        return cls(h, nq)
+
+    def close(self):
+        if self._h:
+            lib.vsa_queries_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Result:
+    """A match list resident in HBM (vsa_result)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @property
+    def count(self):
+        return int(lib.vsa_result_count(self._h))
+
+    def stats(self):
+        s = Stats()
+        _check(lib.vsa_result_getstats(self._h, C.byref(s)))
+        return s
+
+    def fetch(self):
+        n = self.count
+        out = np.zeros(n, MATCH_DTYPE)
+        if n:
+            _check(lib.vsa_result_fetch(self._h, _ptr(out), n))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.vsa_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def findcompletematches(index, queries):
+    """vmatch -complete -q (Vmengine/fcomplete.c:263).  On the reference's
+    short-query error the VsaError carries the matches found before it in
+    .partial."""
+    h = C.c_void_p()
+    rc = lib.vsa_findcompletematches(index._h, queries._h, C.byref(h))
+    res = Result(h) if h else None
+    if rc != 0:
+        e = VsaError(rc, messagespace())
+        e.partial = res
+        raise e
+    return res
+
+
+def findquerymatches(index, queries, searchlength, mum=False, cand=False):
+    """vmatch [-mum [cand]] -l L -q (Vmengine/fquery.c:1009)."""
+    h = C.c_void_p()
+    _check(lib.vsa_findquerymatches(index._h, queries._h, int(mum),
+                                    int(cand), int(searchlength),
+                                    C.byref(h)))
+    return Result(h)
+
+
+def findmaximaluniquematches(index, searchlength):
+    """vmatch -mum -l L IDX (Vmengine/fmumself.c:10)."""
+    h = C.c_void_p()
+    _check(lib.vsa_findmaximaluniquematches(index._h, int(searchlength),
+                                            C.byref(h)))
+    return Result(h)
+
+
+def _collector(stop_after=None):
+    got = []
+
+    def cb(info, mptr):
+        m = np.frombuffer((C.c_uint64 * 4).from_address(mptr), np.uint64)
+        got.append(tuple(int(x) for x in m))
+        if stop_after is not None and len(got) >= stop_after:
+            return 1
+        return 0
+    return got, PROCESSMATCH(cb)
+
+
+def findcompletematches_cb(index, queries, stop_after=None):
+    got, cb = _collector(stop_after)
+    rc = lib.vsa_findcompletematches_cb(index._h, queries._h, cb, None)
+    return rc, got
+
+
+def findquerymatches_cb(index, queries, searchlength, mum=False, cand=False,
+                        stop_after=None):
+    got, cb = _collector(stop_after)
+    rc = lib.vsa_findquerymatches_cb(index._h, queries._h, int(mum),
+                                     int(cand), int(searchlength), cb, None)
+    return rc, got
+
+
+def findmaximaluniquematches_cb(index, searchlength, stop_after=None):
+    got, cb = _collector(stop_after)
+    rc = lib.vsa_findmaximaluniquematches_cb(index._h, int(searchlength), cb,
+                                             None)
+    return rc, got
+
+
+# ---- synthetic inputs ------------------------------
+
+GENOME_SEED = 42
+QUERY_SEED = 4242
+
+
+def synth_genome(n, seed=GENOME_SEED):
+    g = np.zeros(n, np.uint8)
+    lib.vsa_synth_genome(seed, n, _ptr(g))
+    return g
+
+
+def synth_queries(genome, nq, m, seed=QUERY_SEED):
+    genome = np.ascontiguousarray(genome, np.uint8)
+    q = np.zeros(nq * m, np.uint8)
+    lib.vsa_synth_queries(seed, _ptr(genome), genome.shape[0], nq, m,
+                          _ptr(q), None)
+    return q
+
+
+def synth_query_plan(n, nq, m, seed=QUERY_SEED):
+    pos = np.zeros(nq, np.uint64)
+    sub = np.zeros(nq, np.uint32)
+    step = np.zeros(nq, np.uint8)
+    lib.vsa_synth_query_plan(seed, n, nq, m, _ptr(pos), _ptr(sub),
+                             _ptr(step))
+    return pos, sub, step
+
+
+def device_count():
+    return int(lib.vsa_device_count())
+
+
+def device_malloc(nbytes, device=0):
+    p = C.c_void_p()
+    _check(lib.vsa_device_malloc(nbytes, device, C.byref(p)))
+    return p
+
+
+def device_free(p, device=0):
+    _check(lib.vsa_device_free(p, device))
+
+
+def measure_stream_read(nbytes=1 << 30, device=0):
+    g = C.c_double()
+    _check(lib.vsa_measure_stream_read(nbytes, device, C.byref(g)))
+    return g.value

@@ -1,0 +1,589 @@
+// Handles of the C ABI (include/vstree_amd.h): index upload, query batches,
+// result lists, device utilities.
+#include "vsa_internal.hpp"
+#include <algorithm>
+
+static thread_local char g_errbuf[VSA_ERRBUF_SIZE] = "";
+
+extern "C" char *vsa_errbuf()
+{
+  return g_errbuf;
+}
+
+extern "C" const char *vsa_messagespace(void)
+{
+  return g_errbuf;
+}
+
+int vsa_set_device(int device)
+{
+  VSA_HIP(hipSetDevice(device));
+  return 0;
+}
+
+extern "C" int vsa_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+  {
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int vsa_device_malloc(uint64_t bytes, int device, void **ptr)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipMalloc(ptr, bytes > 0 ? bytes : 16));
+  return 0;
+}
+
+extern "C" int vsa_device_free(void *ptr, int device)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipFree(ptr));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------
+
+namespace
+{
+
+// host table with `bits`-wide entries -> device array with `isize`-byte
+// entries; converted through a bounded staging buffer
+int upload_integers(const void *host, uint32_t bits, uint64_t count,
+                    uint32_t isize, void *dev, hipStream_t stream)
+{
+  if (count == 0)
+  {
+    return 0;
+  }
+  if (bits == isize * 8)
+  {
+    VSA_HIP(hipMemcpyAsync(dev, host, count * isize, hipMemcpyHostToDevice,
+                           stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+  const uint64_t chunk = 1ull << 24;
+  std::vector<uint8_t> stage(chunk * isize);
+  for (uint64_t done = 0; done < count; done += chunk)
+  {
+    const uint64_t m = std::min(chunk, count - done);
+    if (bits == 64) // 64 -> 32
+    {
+      const uint64_t *src = (const uint64_t *) host + done;
+      uint32_t *dst = (uint32_t *) stage.data();
+      for (uint64_t i = 0; i < m; i++)
+      {
+        dst[i] = (uint32_t) src[i];
+      }
+    } else // 32 -> 64
+    {
+      const uint32_t *src = (const uint32_t *) host + done;
+      uint64_t *dst = (uint64_t *) stage.data();
+      for (uint64_t i = 0; i < m; i++)
+      {
+        dst[i] = src[i];
+      }
+    }
+    VSA_HIP(hipMemcpyAsync((uint8_t *) dev + done * isize, stage.data(),
+                           m * isize, hipMemcpyHostToDevice, stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+uint64_t powu64(uint64_t b, uint32_t e)
+{
+  uint64_t r = 1;
+  while (e-- > 0)
+  {
+    r *= b;
+  }
+  return r;
+}
+
+} // namespace
+
+// allocates the device tables of an index of the given shape; contents are
+// filled by the caller (upload or the GPU builder)
+int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
+                    uint64_t nllv, bool withbwt, int device,
+                    vsa_index **out)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  vsa_index *ix = new vsa_index;
+  memset((void *) ix, 0, sizeof *ix);
+  ix->device = device;
+  ix->n = n;
+  ix->pl = pl;
+  ix->numofchars = numofchars;
+  ix->nllv = nllv;
+  ix->numofcodes = powu64(numofchars, pl);
+  ix->isize = (n + 1 <= 0xFFFFFFFFull) ? 4 : 8;
+  *out = ix;
+  VSA_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  const uint64_t tisbytes = VSA_TIS_FRONTPAD + n + VSA_TIS_BACKPAD,
+                 sufbytes = (n + 1) * ix->isize, lcpbytes = n + 1 + 32,
+                 llvbytes = 2 * nllv * ix->isize + 16,
+                 bckbytes = 2 * ix->numofcodes * ix->isize;
+  VSA_HIP(hipMalloc((void **) &ix->tis_alloc, tisbytes));
+  VSA_HIP(hipMalloc(&ix->suf, sufbytes));
+  VSA_HIP(hipMalloc((void **) &ix->lcp, lcpbytes));
+  VSA_HIP(hipMalloc(&ix->llv, llvbytes));
+  VSA_HIP(hipMalloc(&ix->bck, bckbytes));
+  ix->device_bytes = tisbytes + sufbytes + lcpbytes + llvbytes + bckbytes;
+  if (withbwt)
+  {
+    VSA_HIP(hipMalloc((void **) &ix->bwt, n + 1 + 32));
+    ix->device_bytes += n + 1 + 32;
+  }
+  // pads: separator symbols around the text, zeros behind lcp
+  VSA_HIP(hipMemsetAsync(ix->tis_alloc, 0xFF, VSA_TIS_FRONTPAD, ix->stream));
+  VSA_HIP(hipMemsetAsync(ix->tis_alloc + VSA_TIS_FRONTPAD + n, 0xFF,
+                         VSA_TIS_BACKPAD, ix->stream));
+  VSA_HIP(hipMemsetAsync(ix->lcp + n + 1, 0, 32, ix->stream));
+  VSA_HIP(hipStreamSynchronize(ix->stream));
+  return 0;
+}
+
+extern "C" void vsa_index_close(vsa_index *ix)
+{
+  if (ix == nullptr)
+  {
+    return;
+  }
+  (void) hipSetDevice(ix->device);
+  (void) hipFree(ix->tis_alloc);
+  (void) hipFree(ix->suf);
+  (void) hipFree(ix->lcp);
+  (void) hipFree(ix->llv);
+  (void) hipFree(ix->bck);
+  (void) hipFree(ix->bwt);
+  if (ix->stream != nullptr)
+  {
+    (void) hipStreamDestroy(ix->stream);
+  }
+  delete ix;
+}
+
+extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
+                                     vsa_index **index)
+{
+  if (t == nullptr || index == nullptr)
+  {
+    VSA_ERROR("vsa_index_from_tables: NULL argument");
+    return -1;
+  }
+  *index = nullptr;
+  // kurtz-basic/multiseq-adv.c:1856-1898 rejects an index whose integer
+  // size does not fit the program; here both widths are accepted
+  if (t->integersize != 32 && t->integersize != 64)
+  {
+    VSA_ERROR("integersize=%u: only 32 and 64 bit indexes are supported",
+              t->integersize);
+    return -2;
+  }
+  if (t->tis == nullptr || t->suf == nullptr || t->lcp == nullptr ||
+      t->bck == nullptr || (t->largelcpvalues > 0 && t->llv == nullptr))
+  {
+    VSA_ERROR("tables tis, suf, lcp, bck (and llv) are required");
+    return -3;
+  }
+  if (t->prefixlength == 0 || t->numofchars == 0 || t->numofchars > 253)
+  {
+    VSA_ERROR("prefixlength=%u numofchars=%u: not a usable bucket table",
+              t->prefixlength, t->numofchars);
+    return -4;
+  }
+  vsa_index *ix = nullptr;
+  int rc = vsa_index_alloc(t->totallength, t->prefixlength, t->numofchars,
+                           t->largelcpvalues, t->bwt != nullptr, device, &ix);
+  if (rc != 0)
+  {
+    vsa_index_close(ix);
+    return rc;
+  }
+  ix->querysepposition = t->querysepposition;
+  ix->hasindexedqueries = t->hasindexedqueries;
+  const uint64_t n = ix->n;
+  hipStream_t s = ix->stream;
+  auto fail = [&](int code) {
+    vsa_index_close(ix);
+    return code;
+  };
+  if (n > 0 &&
+      hipMemcpyAsync(ix->tis_alloc + VSA_TIS_FRONTPAD, t->tis, n,
+                     hipMemcpyHostToDevice, s) != hipSuccess)
+  {
+    VSA_ERROR("upload of tis failed");
+    return fail(-100);
+  }
+  if (hipMemcpyAsync(ix->lcp, t->lcp, n + 1, hipMemcpyHostToDevice, s) !=
+      hipSuccess)
+  {
+    VSA_ERROR("upload of lcp failed");
+    return fail(-100);
+  }
+  if (t->bwt != nullptr &&
+      hipMemcpyAsync(ix->bwt, t->bwt, n + 1, hipMemcpyHostToDevice, s) !=
+          hipSuccess)
+  {
+    VSA_ERROR("upload of bwt failed");
+    return fail(-100);
+  }
+  if (hipStreamSynchronize(s) != hipSuccess)
+  {
+    VSA_ERROR("upload failed");
+    return fail(-100);
+  }
+  if (upload_integers(t->suf, t->integersize, n + 1, ix->isize, ix->suf, s) ||
+      upload_integers(t->bck, t->integersize, 2 * ix->numofcodes, ix->isize,
+                      ix->bck, s) ||
+      upload_integers(t->llv, t->integersize, 2 * ix->nllv, ix->isize,
+                      ix->llv, s))
+  {
+    return fail(-100);
+  }
+  *index = ix;
+  return 0;
+}
+
+extern "C" int vsa_index_getinfo(const vsa_index *ix, vsa_index_info *info)
+{
+  if (ix == nullptr || info == nullptr)
+  {
+    VSA_ERROR("vsa_index_getinfo: NULL argument");
+    return -1;
+  }
+  info->totallength = ix->n;
+  info->numofcodes = ix->numofcodes;
+  info->largelcpvalues = ix->nllv;
+  info->device_bytes = ix->device_bytes;
+  info->prefixlength = ix->pl;
+  info->numofchars = ix->numofchars;
+  info->device_integersize = ix->isize * 8;
+  info->device = ix->device;
+  info->hasindexedqueries = ix->hasindexedqueries;
+  info->hasbwt = ix->bwt != nullptr;
+  return 0;
+}
+
+extern "C" int vsa_index_download(const vsa_index *ix, uint8_t *tis,
+                                  void *suf, uint8_t *lcp, void *llv,
+                                  void *bck, uint8_t *bwt)
+{
+  if (ix == nullptr)
+  {
+    VSA_ERROR("vsa_index_download: NULL argument");
+    return -1;
+  }
+  if (vsa_set_device(ix->device) != 0)
+  {
+    return -100;
+  }
+  const uint64_t n = ix->n;
+  if (tis != nullptr && n > 0)
+  {
+    VSA_HIP(hipMemcpy(tis, ix->tis_alloc + VSA_TIS_FRONTPAD, n,
+                      hipMemcpyDeviceToHost));
+  }
+  if (suf != nullptr)
+  {
+    VSA_HIP(hipMemcpy(suf, ix->suf, (n + 1) * ix->isize,
+                      hipMemcpyDeviceToHost));
+  }
+  if (lcp != nullptr)
+  {
+    VSA_HIP(hipMemcpy(lcp, ix->lcp, n + 1, hipMemcpyDeviceToHost));
+  }
+  if (llv != nullptr && ix->nllv > 0)
+  {
+    VSA_HIP(hipMemcpy(llv, ix->llv, 2 * ix->nllv * ix->isize,
+                      hipMemcpyDeviceToHost));
+  }
+  if (bck != nullptr)
+  {
+    VSA_HIP(hipMemcpy(bck, ix->bck, 2 * ix->numofcodes * ix->isize,
+                      hipMemcpyDeviceToHost));
+  }
+  if (bwt != nullptr && ix->bwt != nullptr)
+  {
+    VSA_HIP(hipMemcpy(bwt, ix->bwt, n + 1, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// queries
+// ---------------------------------------------------------------------------
+
+extern "C" void vsa_queries_free(vsa_queries *q)
+{
+  if (q == nullptr)
+  {
+    return;
+  }
+  (void) hipSetDevice(q->device);
+  (void) hipFree(q->symbols);
+  (void) hipFree(q->start);
+  (void) hipFree(q->length);
+  delete q;
+}
+
+namespace
+{
+
+void summarise_lengths(vsa_queries *q)
+{
+  q->minlength = ~0ull;
+  q->maxlength = 0;
+  for (uint64_t v : q->hlength)
+  {
+    q->minlength = std::min(q->minlength, v);
+    q->maxlength = std::max(q->maxlength, v);
+  }
+  if (q->hlength.empty())
+  {
+    q->minlength = 0;
+  }
+  q->uniform = !q->hlength.empty() && q->minlength == q->maxlength;
+}
+
+} // namespace
+
+extern "C" int vsa_queries_from_host(const uint8_t *symbols,
+                                     uint64_t nsymbols, const uint64_t *start,
+                                     const uint64_t *length, uint64_t nq,
+                                     int device, vsa_queries **queries)
+{
+  if (queries == nullptr || (nq > 0 && (start == nullptr ||
+                                        length == nullptr)) ||
+      (nsymbols > 0 && symbols == nullptr))
+  {
+    VSA_ERROR("vsa_queries_from_host: NULL argument");
+    return -1;
+  }
+  *queries = nullptr;
+  for (uint64_t i = 0; i < nq; i++)
+  {
+    if (start[i] > nsymbols || length[i] > nsymbols - start[i])
+    {
+      VSA_ERROR("query %lu [%lu, +%lu) lies outside the symbol buffer of "
+                "%lu symbols",
+                (unsigned long) i, (unsigned long) start[i],
+                (unsigned long) length[i], (unsigned long) nsymbols);
+      return -2;
+    }
+  }
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  vsa_queries *q = new vsa_queries;
+  q->device = device;
+  q->nq = nq;
+  q->nsymbols = nsymbols;
+  q->symbols = nullptr;
+  q->start = q->length = nullptr;
+  q->hlength.assign(length, length + nq);
+  summarise_lengths(q);
+  *queries = q;
+  VSA_HIP(hipMalloc((void **) &q->symbols, nsymbols + VSA_QUERY_BACKPAD));
+  VSA_HIP(hipMalloc((void **) &q->start, (nq + 1) * 8));
+  VSA_HIP(hipMalloc((void **) &q->length, (nq + 1) * 8));
+  if (nsymbols > 0)
+  {
+    VSA_HIP(hipMemcpy(q->symbols, symbols, nsymbols, hipMemcpyHostToDevice));
+  }
+  VSA_HIP(hipMemset(q->symbols + nsymbols, 0xFF, VSA_QUERY_BACKPAD));
+  if (nq > 0)
+  {
+    VSA_HIP(hipMemcpy(q->start, start, nq * 8, hipMemcpyHostToDevice));
+    VSA_HIP(hipMemcpy(q->length, length, nq * 8, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+__global__ void k_uniform_starts(uint64_t *start, uint64_t *length,
+                                 uint64_t nq, uint64_t m)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq)
+  {
+    start[i] = i * m;
+    length[i] = m;
+  }
+}
+
+extern "C" int vsa_queries_from_device(const void *device_symbols,
+                                       uint64_t nq, uint32_t m, int device,
+                                       vsa_queries **queries)
+{
+  if (queries == nullptr || (nq > 0 && device_symbols == nullptr))
+  {
+    VSA_ERROR("vsa_queries_from_device: NULL argument");
+    return -1;
+  }
+  *queries = nullptr;
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  vsa_queries *q = new vsa_queries;
+  q->device = device;
+  q->nq = nq;
+  q->nsymbols = nq * (uint64_t) m;
+  q->symbols = nullptr;
+  q->start = q->length = nullptr;
+  q->hlength.assign(nq, (uint64_t) m);
+  summarise_lengths(q);
+  *queries = q;
+  VSA_HIP(hipMalloc((void **) &q->symbols,
+                    q->nsymbols + VSA_QUERY_BACKPAD));
+  VSA_HIP(hipMalloc((void **) &q->start, (nq + 1) * 8));
+  VSA_HIP(hipMalloc((void **) &q->length, (nq + 1) * 8));
+  if (q->nsymbols > 0)
+  {
+    VSA_HIP(hipMemcpy(q->symbols, device_symbols, q->nsymbols,
+                      hipMemcpyDeviceToDevice));
+  }
+  VSA_HIP(hipMemset(q->symbols + q->nsymbols, 0xFF, VSA_QUERY_BACKPAD));
+  if (nq > 0)
+  {
+    k_uniform_starts<<<(unsigned int) ((nq + 255) / 256), 256>>>(
+        q->start, q->length, nq, m);
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// results
+// ---------------------------------------------------------------------------
+
+extern "C" uint64_t vsa_result_count(const vsa_result *r)
+{
+  return r == nullptr ? 0 : r->count;
+}
+
+extern "C" int vsa_result_getstats(const vsa_result *r, vsa_stats *stats)
+{
+  if (r == nullptr || stats == nullptr)
+  {
+    VSA_ERROR("vsa_result_getstats: NULL argument");
+    return -1;
+  }
+  *stats = r->stats;
+  return 0;
+}
+
+extern "C" int vsa_result_fetch(const vsa_result *r, vsa_match *matches,
+                                uint64_t capacity)
+{
+  if (r == nullptr || (matches == nullptr && capacity > 0))
+  {
+    VSA_ERROR("vsa_result_fetch: NULL argument");
+    return -1;
+  }
+  const uint64_t m = std::min(capacity, r->count);
+  if (m == 0)
+  {
+    return 0;
+  }
+  if (vsa_set_device(r->device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipMemcpy(matches, r->matches, m * sizeof(vsa_match),
+                    hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" const void *vsa_result_device_matches(const vsa_result *r)
+{
+  return r == nullptr ? nullptr : r->matches;
+}
+
+extern "C" void vsa_result_free(vsa_result *r)
+{
+  if (r == nullptr)
+  {
+    return;
+  }
+  (void) hipSetDevice(r->device);
+  (void) hipFree(r->matches);
+  delete r;
+}
+
+// ---------------------------------------------------------------------------
+// streaming-read probe: the measured denominator next to the 8 TB/s spec
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_stream_read(const uint4 *__restrict__ p, uint64_t n16,
+              unsigned long long *sink)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  for (; i < n16; i += stride)
+  {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) // practically never: keeps the loads alive
+  {
+    atomicAdd(sink, 1ull);
+  }
+}
+
+extern "C" int vsa_measure_stream_read(uint64_t bytes, int device,
+                                       double *gbps)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  void *buf = nullptr;
+  unsigned long long *sink = nullptr;
+  const uint64_t n16 = bytes / 16;
+  VSA_HIP(hipMalloc(&buf, n16 * 16 + 16));
+  VSA_HIP(hipMalloc((void **) &sink, 8));
+  VSA_HIP(hipMemset(buf, 1, n16 * 16));
+  VSA_HIP(hipMemset(sink, 0, 8));
+  hipEvent_t a, b;
+  VSA_HIP(hipEventCreate(&a));
+  VSA_HIP(hipEventCreate(&b));
+  const int reps = 5;
+  k_stream_read<<<256 * 8, 256>>>((const uint4 *) buf, n16, sink); // warm up
+  VSA_HIP(hipEventRecord(a, 0));
+  for (int r = 0; r < reps; r++)
+  {
+    k_stream_read<<<256 * 8, 256>>>((const uint4 *) buf, n16, sink);
+  }
+  VSA_HIP(hipEventRecord(b, 0));
+  VSA_HIP(hipEventSynchronize(b));
+  float ms = 0;
+  VSA_HIP(hipEventElapsedTime(&ms, a, b));
+  *gbps = (double) (n16 * 16) * reps / ((double) ms * 1e-3) / 1e9;
+  (void) hipEventDestroy(a);
+  (void) hipEventDestroy(b);
+  (void) hipFree(buf);
+  (void) hipFree(sink);
+  return 0;
+}

@@ -1,0 +1,1148 @@
+// Search kernels of the Vmengine query path on MI355X and their host-side
+// pipelines.  Kernel inventory (DESIGN.md has the byte budgets):
+//
+//   K1  k_complete_search   one work-item per query: bucket -> lcp-aware
+//                           binary search -> lcptab widening; writes the
+//                           suffix-array interval [left, left+count)
+//       k_complete_expand   one work-item per match (load-balanced over the
+//                           scanned counts): suf[left+k] -> vsa_match
+//   K2  k_query_search      one work-item per query suffix: bucket -> binary
+//                           search -> MEM enumeration or MUM-candidate test;
+//                           wavefront-aggregated append, then a stable radix
+//                           sort by work-item number restores reference order
+//   K4  k_mum_*             candidates sorted by (dbstart asc, length desc),
+//                           prefix-max scan, flag, compact
+//                           (kurtz/cleanMUMcand.c:55-118)
+//   K3  k_selfmum_scan      streaming scan over lcptab for indexes that hold
+//                           their queries (Vmengine/fmumself.c:10-66)
+//
+// rocPRIM supplies radix sort / scan / select / reduce only.
+#include <cstring>
+#include <algorithm>
+#include "esa_device.hpp"
+#include <rocprim/rocprim.hpp>
+
+#define VSA_BLOCK 256
+
+// ---------------------------------------------------------------------------
+// K1: exact complete matches (Vmengine/exactcompl.c:168-216)
+// ---------------------------------------------------------------------------
+
+// findsufboundaries, Vmengine/exactcompl.c:64-140: widen from the witness to
+// all suffixes sharing >= least symbols, inside the bucket [vleft, vright]
+template <typename IDX>
+__device__ __forceinline__ void
+vsa_findsufboundaries(const DevIndex<IDX> &ix, uint32_t maxlcp,
+                      uint64_t witness, uint32_t least, uint64_t vleft,
+                      uint64_t vright, uint64_t &l, uint64_t &r)
+{
+  uint64_t i;
+
+  if (maxlcp < 255)
+  {
+    for (i = witness; i != vleft && ix.lcp[i] >= (uint8_t) least; i--)
+    {
+    }
+    l = i;
+    for (i = witness + 1; i <= vright && ix.lcp[i] >= (uint8_t) least; i++)
+    {
+    }
+    r = i - 1;
+  } else
+  {
+    for (i = witness; i != vleft && vsa_evallcp(ix, i) >= least; i--)
+    {
+    }
+    l = i;
+    for (i = witness + 1; i <= vright && vsa_evallcp(ix, i) >= least; i++)
+    {
+    }
+    r = i - 1;
+  }
+}
+
+template <typename IDX>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_complete_search(const DevIndex<IDX> ix, const DevQueries qs,
+                  uint64_t qlimit, uint64_t *__restrict__ outleft,
+                  uint64_t *__restrict__ outcount)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+
+  if (q >= qlimit)
+  {
+    return;
+  }
+  const uint8_t *pattern = qs.symbols + qs.start[q];
+  const uint32_t plen = (uint32_t) qs.length[q];
+  uint64_t vleft, vright, l = 0, count = 0;
+
+  if (vsa_bucket(ix, pattern, vleft, vright))
+  {
+    uint32_t maxlcp;
+    uint64_t witness, r;
+
+    vsa_findmaxprefixlen(ix, vleft, vright, ix.pl, pattern, plen, maxlcp,
+                         witness);
+    if (maxlcp >= plen)
+    {
+      vsa_findsufboundaries(ix, maxlcp, witness, plen, vleft, vright, l, r);
+      count = r - l + 1;
+    }
+  }
+  outleft[q] = l;
+  outcount[q] = count;
+}
+
+// processfinalexactmatchinterval, Vmengine/exactcompl.c:142-166, for all
+// queries at once: match t belongs to the query whose scanned count range
+// contains t
+template <typename IDX>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_complete_expand(const DevIndex<IDX> ix, const DevQueries qs, uint64_t nq,
+                  const uint64_t *__restrict__ left,
+                  const uint64_t *__restrict__ offsets, uint64_t total,
+                  vsa_match *__restrict__ out)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+
+  if (t >= total)
+  {
+    return;
+  }
+  // largest q with offsets[q] <= t (offsets has nq+1 entries, last = total)
+  uint64_t lo = 0, hi = nq;
+  while (hi - lo > 1)
+  {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= t)
+    {
+      lo = mid;
+    } else
+    {
+      hi = mid;
+    }
+  }
+  vsa_match m;
+  m.length = qs.length[lo];
+  m.dbstart = (uint64_t) ix.suf[left[lo] + (t - offsets[lo])];
+  m.queryseq = lo;
+  m.querystart = 0;
+  out[t] = m;
+}
+
+// ---------------------------------------------------------------------------
+// K2: matches of all query suffixes (kurtz/matchsub.c:165-235 driving
+// Vmengine/fquery.c:139-270 / :297-386)
+// ---------------------------------------------------------------------------
+
+// macro PROCESSSUFFIX, Vmengine/fquery.c:54-81: a match is reported iff it
+// cannot be extended to the left
+template <typename IDX>
+__device__ __forceinline__ bool vsa_leftmaximal(const DevIndex<IDX> &ix,
+                                                uint64_t sufstart,
+                                                uint8_t leftchar)
+{
+  return sufstart == 0 || VSA_ISSPECIAL(leftchar) ||
+         leftchar != ix.tis[sufstart - 1];
+}
+
+// leftrightsubmatch, Vmengine/fquery.c:139-270 with the bounds algorithm 2
+// passes (left = 0, right = totallength-1, kurtz/matchsub.c:504-515).
+// WRITE = false counts the reports, WRITE = true stores them at out[0..).
+template <typename IDX, bool WRITE>
+__device__ __forceinline__ uint32_t
+vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
+             uint8_t leftchar, uint32_t searchlength, uint64_t qseq,
+             uint64_t qoff, vsa_match *out, uint64_t *outkey, uint64_t key)
+{
+  const uint64_t right = ix.n - 1;
+  uint32_t c = 0, minprefix = maxlcp;
+  uint64_t idx, lcpval;
+
+#define VSA_REPORT(I, LEN)                                                    \
+  {                                                                           \
+    const uint64_t ss_ = (uint64_t) ix.suf[I];                                \
+    if (vsa_leftmaximal(ix, ss_, leftchar))                                   \
+    {                                                                         \
+      if (WRITE)                                                              \
+      {                                                                       \
+        vsa_match m_;                                                         \
+        m_.length = (LEN);                                                    \
+        m_.dbstart = ss_;                                                     \
+        m_.queryseq = qseq;                                                   \
+        m_.querystart = qoff;                                                 \
+        out[c] = m_;                                                          \
+        outkey[c] = key;                                                      \
+      }                                                                       \
+      c++;                                                                    \
+    }                                                                         \
+  }
+
+  for (idx = witness;; idx--)
+  {
+    VSA_REPORT(idx, minprefix);
+    if (idx == 0)
+    {
+      break;
+    }
+    lcpval = (maxlcp < 255) ? (uint64_t) ix.lcp[idx] : vsa_evallcp(ix, idx);
+    if (lcpval < searchlength)
+    {
+      break;
+    }
+    if (minprefix > lcpval)
+    {
+      minprefix = (uint32_t) lcpval;
+    }
+  }
+  minprefix = maxlcp;
+  for (idx = witness + 1; idx <= right; idx++)
+  {
+    lcpval = (maxlcp < 255) ? (uint64_t) ix.lcp[idx] : vsa_evallcp(ix, idx);
+    if (lcpval < searchlength)
+    {
+      break;
+    }
+    if (minprefix > lcpval)
+    {
+      minprefix = (uint32_t) lcpval;
+    }
+    VSA_REPORT(idx, minprefix);
+  }
+#undef VSA_REPORT
+  return c;
+}
+
+// leftrightmaximaluniquematch, Vmengine/fquery.c:297-386, bounds as above.
+// The reference's branch for maxlcp >= 255 looks at the right neighbour only
+// if witness + 1 < right; kept as it stands.
+template <typename IDX>
+__device__ __forceinline__ bool
+vsa_mum_candidate(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness)
+{
+  const uint64_t right = ix.n - 1;
+
+  if (maxlcp < 255)
+  {
+    return (witness == 0 || ix.lcp[witness] < (uint8_t) maxlcp) &&
+           (witness + 1 > right || ix.lcp[witness + 1] < (uint8_t) maxlcp);
+  }
+  bool okay = (witness == 0) || vsa_evallcp(ix, witness) < maxlcp;
+  if (okay && witness + 1 < right)
+  {
+    okay = vsa_evallcp(ix, witness + 1) < maxlcp;
+  }
+  return okay;
+}
+
+// Work-item t of the batch = (query q, offset off).  Queries of one length:
+// arithmetic; ragged batches: binary search in the scanned per-query counts.
+__device__ __forceinline__ void
+vsa_decode_workitem(const DevQueries &qs, const uint64_t *__restrict__ base,
+                    uint32_t perquery, uint64_t t, uint64_t &q, uint32_t &off)
+{
+  if (base == nullptr)
+  {
+    q = t / perquery;
+    off = (uint32_t) (t - q * perquery);
+  } else
+  {
+    uint64_t lo = 0, hi = qs.nq;
+    while (hi - lo > 1)
+    {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (base[mid] <= t)
+      {
+        lo = mid;
+      } else
+      {
+        hi = mid;
+      }
+    }
+    q = lo;
+    off = (uint32_t) (t - base[lo]);
+  }
+}
+
+template <typename IDX, bool MUM>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
+               const uint64_t *__restrict__ base, uint32_t perquery,
+               uint64_t nitems, uint32_t searchlength,
+               vsa_match *__restrict__ out, uint64_t *__restrict__ outkey,
+               uint64_t capacity, unsigned long long *__restrict__ cursor)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const bool active = t < nitems;
+  uint32_t c = 0, maxlcp = 0, off = 0;
+  uint64_t witness = 0, q = 0;
+  uint8_t leftchar = (uint8_t) VSA_SEPARATOR;
+  bool found = false;
+
+  if (active)
+  {
+    vsa_decode_workitem(qs, base, perquery, t, q, off);
+    const uint8_t *qptr = qs.symbols + qs.start[q] + off;
+    const uint32_t remaining = (uint32_t) qs.length[q] - off;
+    uint64_t vleft, vright;
+
+    if (off > 0)
+    {
+      leftchar = qptr[-1];
+    }
+    if (vsa_bucket(ix, qptr, vleft, vright))
+    {
+      vsa_findmaxprefixlen(ix, vleft, vright, ix.pl, qptr, remaining, maxlcp,
+                           witness);
+      found = maxlcp >= searchlength;
+    }
+    if (found)
+    {
+      if (MUM)
+      {
+        c = (vsa_mum_candidate(ix, maxlcp, witness) &&
+             vsa_leftmaximal(ix, (uint64_t) ix.suf[witness], leftchar))
+                ? 1u
+                : 0u;
+      } else
+      {
+        c = vsa_mem_walk<IDX, false>(ix, maxlcp, witness, leftchar,
+                                     searchlength, q, off, nullptr, nullptr,
+                                     t);
+      }
+    }
+  }
+  // all 64 lanes arrive here
+  const uint64_t mybase = vsa_wave_reserve(cursor, c);
+  if (c > 0 && mybase + c <= capacity)
+  {
+    if (MUM)
+    {
+      vsa_match m;
+      m.length = maxlcp;
+      m.dbstart = (uint64_t) ix.suf[witness];
+      m.queryseq = q;
+      m.querystart = off;
+      out[mybase] = m;
+      outkey[mybase] = t;
+    } else
+    {
+      vsa_mem_walk<IDX, true>(ix, maxlcp, witness, leftchar, searchlength, q,
+                              off, out + mybase, outkey + mybase, t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4: MUM candidates -> MUMs (kurtz/cleanMUMcand.c:55-118)
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_keys(const vsa_match *__restrict__ cand, uint64_t n,
+           uint64_t *__restrict__ keylen, uint64_t *__restrict__ keydb)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    keylen[i] = ~cand[i].length; // decreasing length
+    keydb[i] = cand[i].dbstart;
+  }
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_rightends(const vsa_match *__restrict__ cand, uint64_t n,
+                uint64_t *__restrict__ rightend)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    rightend[i] = cand[i].dbstart + cand[i].length - 1;
+  }
+}
+
+// dbright[i] = max(0, rightend[0..i)) is what the reference's running
+// variable holds when it looks at candidate i.  Candidate i survives iff it
+// is not covered (dbright < rightend) and its successor does not end at the
+// same position with the same start.
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_flags(const vsa_match *__restrict__ cand,
+            const uint64_t *__restrict__ rightend,
+            const uint64_t *__restrict__ dbright, uint64_t n,
+            uint8_t *__restrict__ keep)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (i >= n)
+  {
+    return;
+  }
+  bool k = dbright[i] < rightend[i];
+  if (k && i + 1 < n)
+  {
+    // dbright[i+1] = rightend[i] here
+    if (rightend[i + 1] == rightend[i] &&
+        cand[i + 1].dbstart == cand[i].dbstart)
+    {
+      k = false;
+    }
+  }
+  keep[i] = k ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// K3: MUMs on an index that contains its queries (Vmengine/fmumself.c:10-66)
+// ---------------------------------------------------------------------------
+
+#define VSA_SCAN_PER_THREAD 16
+
+template <typename IDX>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_selfmum_scan(const DevIndex<IDX> ix, uint64_t searchlength,
+               uint64_t querysepposition, vsa_match *__restrict__ out,
+               uint64_t *__restrict__ outkey, uint64_t capacity,
+               unsigned long long *__restrict__ cursor)
+{
+  // work-item w scans lcp positions i in [16w, 16w+16) intersected with
+  // [2, n); the 16 bytes arrive as one 128-bit load
+  const uint64_t w = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t i0 = w * VSA_SCAN_PER_THREAD;
+  const uint32_t slmin =
+      (uint32_t) (searchlength < 255 ? searchlength : 255);
+  uint32_t c = 0;
+  uint64_t hits = 0; // bit k: position i0+k is a peak that qualifies
+
+  if (i0 < ix.n)
+  {
+    uint8_t b[VSA_SCAN_PER_THREAD + 2];
+    // lcp has n+1 entries and the allocation is padded to a multiple of 16
+    const uint4 v = *reinterpret_cast<const uint4 *>(ix.lcp + i0);
+    __builtin_memcpy(b + 2, &v, 16);
+    b[0] = (i0 >= 2) ? ix.lcp[i0 - 2] : 0;
+    b[1] = (i0 >= 1) ? ix.lcp[i0 - 1] : 0;
+    for (int k = 0; k < VSA_SCAN_PER_THREAD; k++)
+    {
+      const uint64_t i = i0 + k;
+      if (i < 2 || i >= ix.n)
+      {
+        continue;
+      }
+      // bytes first: a peak needs second >= min(searchlength, 255)
+      const uint32_t f8 = b[k], s8 = b[k + 1], t8 = b[k + 2];
+      if (s8 < slmin || f8 > s8 || t8 > s8)
+      {
+        continue;
+      }
+      uint64_t first = f8, second = s8, third = t8;
+      if (s8 == 255)
+      {
+        second = vsa_largelcp(ix, i - 1);
+        first = (f8 == 255) ? vsa_largelcp(ix, i - 2) : f8;
+        third = (t8 == 255) ? vsa_largelcp(ix, i) : t8;
+      }
+      if (second >= searchlength && first < second && third < second)
+      {
+        uint64_t s1 = (uint64_t) ix.suf[i - 2], s2 = (uint64_t) ix.suf[i - 1];
+        if (s1 > s2)
+        {
+          const uint64_t tmp = s1;
+          s1 = s2;
+          s2 = tmp;
+        }
+        if (s1 < querysepposition && s2 > querysepposition)
+        {
+          uint8_t a, bb;
+          if (s1 == 0 || VSA_ISSPECIAL(a = ix.bwt[i - 1]) ||
+              VSA_ISSPECIAL(bb = ix.bwt[i - 2]) || a != bb)
+          {
+            hits |= 1ull << k;
+            c++;
+          }
+        }
+      }
+    }
+  }
+  const uint64_t mybase = vsa_wave_reserve(cursor, c);
+  if (c > 0 && mybase + c <= capacity)
+  {
+    uint32_t j = 0;
+    for (int k = 0; k < VSA_SCAN_PER_THREAD; k++)
+    {
+      if (hits & (1ull << k))
+      {
+        const uint64_t i = i0 + k;
+        uint64_t s1 = (uint64_t) ix.suf[i - 2], s2 = (uint64_t) ix.suf[i - 1];
+        if (s1 > s2)
+        {
+          const uint64_t tmp = s1;
+          s1 = s2;
+          s2 = tmp;
+        }
+        uint64_t len = ix.lcp[i - 1];
+        if (len == 255)
+        {
+          len = vsa_largelcp(ix, i - 1);
+        }
+        vsa_match m;
+        m.length = len;
+        m.dbstart = s1;
+        m.queryseq = s2;
+        m.querystart = 0;
+        out[mybase + j] = m;
+        outkey[mybase + j] = i;
+        j++;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+namespace
+{
+
+struct DevBuf
+{
+  void *p = nullptr;
+  ~DevBuf()
+  {
+    if (p != nullptr)
+    {
+      (void) hipFree(p);
+    }
+  }
+  int alloc(size_t bytes)
+  {
+    if (p != nullptr)
+    {
+      (void) hipFree(p);
+      p = nullptr;
+    }
+    VSA_HIP(hipMalloc(&p, bytes > 0 ? bytes : 16));
+    return 0;
+  }
+  template <typename T>
+  T *as()
+  {
+    return (T *) p;
+  }
+  void *release()
+  {
+    void *r = p;
+    p = nullptr;
+    return r;
+  }
+};
+
+struct Timer
+{
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s;
+  explicit Timer(hipStream_t stream) : s(stream)
+  {
+    (void) hipEventCreate(&a);
+    (void) hipEventCreate(&b);
+  }
+  ~Timer()
+  {
+    (void) hipEventDestroy(a);
+    (void) hipEventDestroy(b);
+  }
+  void start()
+  {
+    (void) hipEventRecord(a, s);
+  }
+  void stop()
+  {
+    (void) hipEventRecord(b, s);
+  }
+  double ms() // after the stream has been synchronised
+  {
+    float f = 0;
+    (void) hipEventElapsedTime(&f, a, b);
+    return (double) f;
+  }
+};
+
+inline unsigned int gridfor(uint64_t items)
+{
+  return (unsigned int) ((items + VSA_BLOCK - 1) / VSA_BLOCK);
+}
+
+struct MatchLength
+{
+  __device__ uint64_t operator()(const vsa_match &m) const
+  {
+    return m.length;
+  }
+};
+
+int sumlengths(const vsa_match *matches, uint64_t n, hipStream_t stream,
+               uint64_t *result)
+{
+  *result = 0;
+  if (n == 0)
+  {
+    return 0;
+  }
+  DevBuf out, temp;
+  size_t tb = 0;
+  auto in = rocprim::make_transform_iterator(matches, MatchLength());
+  if (out.alloc(sizeof(uint64_t)) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::reduce(nullptr, tb, in, out.as<uint64_t>(), (uint64_t) 0,
+                          (size_t) n, rocprim::plus<uint64_t>(), stream));
+  if (temp.alloc(tb) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::reduce(temp.p, tb, in, out.as<uint64_t>(), (uint64_t) 0,
+                          (size_t) n, rocprim::plus<uint64_t>(), stream));
+  VSA_HIP(hipMemcpyAsync(result, out.p, sizeof(uint64_t),
+                         hipMemcpyDeviceToHost, stream));
+  VSA_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+unsigned int bitsfor(uint64_t maxvalue)
+{
+  unsigned int b = 1;
+  while (b < 64 && (maxvalue >> b) != 0)
+  {
+    b++;
+  }
+  return b;
+}
+
+// stable sort of (key, match) pairs by key bits [0, endbit); results land in
+// keys_out / matches_out
+int sortbykey(uint64_t *keys_in, uint64_t *keys_out, vsa_match *in,
+              vsa_match *out, uint64_t n, unsigned int endbit,
+              hipStream_t stream)
+{
+  DevBuf temp;
+  size_t tb = 0;
+  VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, in, out,
+                                    (size_t) n, 0u, endbit, stream));
+  if (temp.alloc(tb) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, keys_in, keys_out, in, out,
+                                    (size_t) n, 0u, endbit, stream));
+  return 0;
+}
+
+vsa_result *newresult(int device)
+{
+  vsa_result *r = new vsa_result;
+  r->device = device;
+  r->count = 0;
+  r->matches = nullptr;
+  memset(&r->stats, 0, sizeof r->stats);
+  return r;
+}
+
+// ---- K1 pipeline ----
+
+template <typename IDX>
+int run_complete(const vsa_index *index, const vsa_queries *queries,
+                 uint64_t qlimit, vsa_result *res)
+{
+  hipStream_t stream = index->stream;
+  Timer tall(stream), tsearch(stream);
+  const DevIndex<IDX> ix = index->view<IDX>();
+  const DevQueries qs = devqueries(queries);
+  DevBuf left, count, offsets, temp, matches;
+  uint64_t total = 0;
+
+  res->stats.searches = qlimit;
+  if (qlimit == 0)
+  {
+    return 0;
+  }
+  if (left.alloc(qlimit * 8) || count.alloc((qlimit + 1) * 8) ||
+      offsets.alloc((qlimit + 1) * 8))
+  {
+    return -100;
+  }
+  tall.start();
+  VSA_HIP(hipMemsetAsync(count.as<uint64_t>() + qlimit, 0, 8, stream));
+  tsearch.start();
+  k_complete_search<IDX><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+      ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+  tsearch.stop();
+  VSA_HIP(hipGetLastError());
+  size_t tb = 0;
+  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, count.as<uint64_t>(),
+                                  offsets.as<uint64_t>(), (uint64_t) 0,
+                                  (size_t) (qlimit + 1),
+                                  rocprim::plus<uint64_t>(), stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, count.as<uint64_t>(),
+                                  offsets.as<uint64_t>(), (uint64_t) 0,
+                                  (size_t) (qlimit + 1),
+                                  rocprim::plus<uint64_t>(), stream));
+  VSA_HIP(hipMemcpyAsync(&total, offsets.as<uint64_t>() + qlimit, 8,
+                         hipMemcpyDeviceToHost, stream));
+  VSA_HIP(hipStreamSynchronize(stream));
+  if (total > 0)
+  {
+    if (matches.alloc(total * sizeof(vsa_match)))
+    {
+      return -100;
+    }
+    k_complete_expand<IDX><<<gridfor(total), VSA_BLOCK, 0, stream>>>(
+        ix, qs, qlimit, left.as<uint64_t>(), offsets.as<uint64_t>(), total,
+        matches.as<vsa_match>());
+    VSA_HIP(hipGetLastError());
+  }
+  tall.stop();
+  VSA_HIP(hipStreamSynchronize(stream));
+  res->count = total;
+  res->matches = (vsa_match *) matches.release();
+  res->stats.count = total;
+  res->stats.search_kernel_ms = tsearch.ms();
+  res->stats.total_device_ms = tall.ms();
+  // every complete match has the length of its query
+  return sumlengths(res->matches, total, stream, &res->stats.sumlength);
+}
+
+// ---- K2 (+K4) pipeline ----
+
+// MUM candidates, any order -> MUMs in dbstart order
+int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
+                     DevBuf &mums, uint64_t *nmums)
+{
+  *nmums = 0;
+  if (ncand == 0)
+  {
+    return 0;
+  }
+  DevBuf k1, k2, kout, m2, ends, dbright, keep, temp, dcount;
+  if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || kout.alloc(ncand * 8) ||
+      m2.alloc(ncand * sizeof(vsa_match)) || ends.alloc(ncand * 8) ||
+      dbright.alloc(ncand * 8) || keep.alloc(ncand) || dcount.alloc(8))
+  {
+    return -100;
+  }
+  // least significant key first: length descending, then stable by dbstart
+  k_mum_keys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+      cand.as<vsa_match>(), ncand, k1.as<uint64_t>(), k2.as<uint64_t>());
+  VSA_HIP(hipGetLastError());
+  if (sortbykey(k1.as<uint64_t>(), kout.as<uint64_t>(), cand.as<vsa_match>(),
+                m2.as<vsa_match>(), ncand, 64, stream))
+  {
+    return -100;
+  }
+  k_mum_keys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+      m2.as<vsa_match>(), ncand, k1.as<uint64_t>(), k2.as<uint64_t>());
+  VSA_HIP(hipGetLastError());
+  if (sortbykey(k2.as<uint64_t>(), kout.as<uint64_t>(), m2.as<vsa_match>(),
+                cand.as<vsa_match>(), ncand, 64, stream))
+  {
+    return -100;
+  }
+  k_mum_rightends<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+      cand.as<vsa_match>(), ncand, ends.as<uint64_t>());
+  VSA_HIP(hipGetLastError());
+  size_t tb = 0;
+  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
+                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  (size_t) ncand, rocprim::maximum<uint64_t>(),
+                                  stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
+                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  (size_t) ncand, rocprim::maximum<uint64_t>(),
+                                  stream));
+  k_mum_flags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+      cand.as<vsa_match>(), ends.as<uint64_t>(), dbright.as<uint64_t>(),
+      ncand, keep.as<uint8_t>());
+  VSA_HIP(hipGetLastError());
+  if (mums.alloc(ncand * sizeof(vsa_match)))
+  {
+    return -100;
+  }
+  tb = 0;
+  VSA_HIP(rocprim::select(nullptr, tb, cand.as<vsa_match>(),
+                          keep.as<uint8_t>(), mums.as<vsa_match>(),
+                          dcount.as<uint64_t>(), (size_t) ncand, stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::select(temp.p, tb, cand.as<vsa_match>(),
+                          keep.as<uint8_t>(), mums.as<vsa_match>(),
+                          dcount.as<uint64_t>(), (size_t) ncand, stream));
+  VSA_HIP(hipMemcpyAsync(nmums, dcount.p, 8, hipMemcpyDeviceToHost, stream));
+  VSA_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+template <typename IDX>
+int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
+              bool domumcand, uint32_t searchlength, vsa_result *res)
+{
+  hipStream_t stream = index->stream;
+  Timer tall(stream), tsearch(stream);
+  const DevIndex<IDX> ix = index->view<IDX>();
+  const DevQueries qs = devqueries(queries);
+  DevBuf base, cursor, out, keys;
+  uint64_t nitems = 0;
+  uint32_t perquery = 0;
+  const uint64_t *dbase = nullptr;
+
+  // work-items: one per query suffix with remaining >= searchlength
+  // (kurtz/matchsub.c:187-196: shorter queries are skipped silently)
+  if (qs.uniformlen != 0)
+  {
+    perquery = (qs.uniformlen >= searchlength)
+                   ? qs.uniformlen - searchlength + 1
+                   : 0;
+    nitems = (uint64_t) perquery * queries->nq;
+  } else
+  {
+    std::vector<uint64_t> hb(queries->nq + 1);
+    for (uint64_t q = 0; q < queries->nq; q++)
+    {
+      hb[q] = nitems;
+      const uint64_t len = queries->hlength[q];
+      nitems += (len >= searchlength) ? len - searchlength + 1 : 0;
+    }
+    hb[queries->nq] = nitems;
+    if (base.alloc(hb.size() * 8))
+    {
+      return -100;
+    }
+    VSA_HIP(hipMemcpyAsync(base.p, hb.data(), hb.size() * 8,
+                           hipMemcpyHostToDevice, stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    dbase = base.as<uint64_t>();
+  }
+  res->stats.searches = nitems;
+  if (nitems == 0)
+  {
+    return 0;
+  }
+  if (cursor.alloc(8))
+  {
+    return -100;
+  }
+  // first guess: MUM modes report at most one match per work-item but
+  // typically about one per query; MEM is unbounded.  The kernel counts what
+  // it needs and never writes past capacity; on overflow run again.
+  uint64_t capacity = std::max<uint64_t>(queries->nq * 2 + 1024, 1 << 16);
+  uint64_t needed = 0;
+  double searchms = 0;
+  tall.start();
+  for (int attempt = 0; attempt < 2; attempt++)
+  {
+    if (out.alloc(capacity * sizeof(vsa_match)) || keys.alloc(capacity * 8))
+    {
+      return -100;
+    }
+    VSA_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    tsearch.start();
+    if (domum)
+    {
+      k_query_search<IDX, true><<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(
+          ix, qs, dbase, perquery, nitems, searchlength, out.as<vsa_match>(),
+          keys.as<uint64_t>(), capacity, cursor.as<unsigned long long>());
+    } else
+    {
+      k_query_search<IDX, false><<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(
+          ix, qs, dbase, perquery, nitems, searchlength, out.as<vsa_match>(),
+          keys.as<uint64_t>(), capacity, cursor.as<unsigned long long>());
+    }
+    tsearch.stop();
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipMemcpyAsync(&needed, cursor.p, 8, hipMemcpyDeviceToHost,
+                           stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    searchms += tsearch.ms();
+    if (needed <= capacity)
+    {
+      break;
+    }
+    capacity = needed;
+  }
+  if (needed > capacity)
+  {
+    VSA_ERROR("match buffer overflow: %llu > %llu",
+              (unsigned long long) needed, (unsigned long long) capacity);
+    return -5;
+  }
+  res->stats.candidates = domum ? needed : 0;
+  if (domum && !domumcand)
+  {
+    DevBuf mums;
+    uint64_t nm = 0;
+    if (mumuniqueinquery(out, needed, stream, mums, &nm))
+    {
+      return -100;
+    }
+    res->count = nm;
+    res->matches = (vsa_match *) mums.release();
+  } else if (needed > 0)
+  {
+    // reference order = work-item order; appends of one work-item are
+    // contiguous and in order, the radix sort is stable
+    DevBuf sk, sm;
+    if (sk.alloc(needed * 8) || sm.alloc(needed * sizeof(vsa_match)))
+    {
+      return -100;
+    }
+    if (sortbykey(keys.as<uint64_t>(), sk.as<uint64_t>(),
+                  out.as<vsa_match>(), sm.as<vsa_match>(), needed,
+                  bitsfor(nitems), stream))
+    {
+      return -100;
+    }
+    res->count = needed;
+    res->matches = (vsa_match *) sm.release();
+  }
+  tall.stop();
+  VSA_HIP(hipStreamSynchronize(stream));
+  res->stats.count = res->count;
+  res->stats.search_kernel_ms = searchms;
+  res->stats.total_device_ms = tall.ms();
+  return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
+}
+
+// ---- K3 pipeline ----
+
+template <typename IDX>
+int run_selfmum(const vsa_index *index, uint64_t searchlength,
+                vsa_result *res)
+{
+  hipStream_t stream = index->stream;
+  Timer tall(stream), tsearch(stream);
+  const DevIndex<IDX> ix = index->view<IDX>();
+  DevBuf cursor, out, keys;
+  const uint64_t nwork =
+      (index->n + VSA_SCAN_PER_THREAD - 1) / VSA_SCAN_PER_THREAD;
+  uint64_t capacity = 1 << 20, needed = 0;
+  double searchms = 0;
+
+  res->stats.searches = index->n;
+  if (cursor.alloc(8))
+  {
+    return -100;
+  }
+  tall.start();
+  for (int attempt = 0; attempt < 2; attempt++)
+  {
+    if (out.alloc(capacity * sizeof(vsa_match)) || keys.alloc(capacity * 8))
+    {
+      return -100;
+    }
+    VSA_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    tsearch.start();
+    k_selfmum_scan<IDX><<<gridfor(nwork), VSA_BLOCK, 0, stream>>>(
+        ix, searchlength, index->querysepposition, out.as<vsa_match>(),
+        keys.as<uint64_t>(), capacity, cursor.as<unsigned long long>());
+    tsearch.stop();
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipMemcpyAsync(&needed, cursor.p, 8, hipMemcpyDeviceToHost,
+                           stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    searchms += tsearch.ms();
+    if (needed <= capacity)
+    {
+      break;
+    }
+    capacity = needed;
+  }
+  if (needed > 0)
+  {
+    DevBuf sk, sm;
+    if (sk.alloc(needed * 8) || sm.alloc(needed * sizeof(vsa_match)))
+    {
+      return -100;
+    }
+    if (sortbykey(keys.as<uint64_t>(), sk.as<uint64_t>(),
+                  out.as<vsa_match>(), sm.as<vsa_match>(), needed,
+                  bitsfor(index->n), stream))
+    {
+      return -100;
+    }
+    res->count = needed;
+    res->matches = (vsa_match *) sm.release();
+  }
+  tall.stop();
+  VSA_HIP(hipStreamSynchronize(stream));
+  res->stats.count = res->count;
+  res->stats.search_kernel_ms = searchms;
+  res->stats.total_device_ms = tall.ms();
+  return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+extern "C" int vsa_findcompletematches(const vsa_index *index,
+                                       const vsa_queries *queries,
+                                       vsa_result **result)
+{
+  if (index == nullptr || queries == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findcompletematches: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (queries->device != index->device)
+  {
+    VSA_ERROR("queries live on device %d, index on device %d",
+              queries->device, index->device);
+    return -1;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  // Vmengine/exactcompl.c:179-185: the first query shorter than
+  // prefixlength stops the run; queries before it are still matched
+  uint64_t qlimit = queries->nq;
+  bool shortquery = false;
+  if (queries->minlength < index->pl)
+  {
+    for (uint64_t q = 0; q < queries->nq; q++)
+    {
+      if (queries->hlength[q] < index->pl)
+      {
+        qlimit = q;
+        shortquery = true;
+        break;
+      }
+    }
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc = (index->isize == 4)
+                     ? run_complete<uint32_t>(index, queries, qlimit, res)
+                     : run_complete<uint64_t>(index, queries, qlimit, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  if (shortquery)
+  {
+    VSA_ERROR("patternlength=%lu must be >= %lu=prefixlen",
+              (unsigned long) queries->hlength[qlimit],
+              (unsigned long) index->pl);
+    return -2;
+  }
+  return 0;
+}
+
+extern "C" int vsa_findquerymatches(const vsa_index *index,
+                                    const vsa_queries *queries,
+                                    int domaximaluniquematch,
+                                    int domaximaluniquematchcandidates,
+                                    uint64_t searchlength,
+                                    vsa_result **result)
+{
+  if (index == nullptr || queries == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findquerymatches: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (queries->device != index->device)
+  {
+    VSA_ERROR("queries live on device %d, index on device %d",
+              queries->device, index->device);
+    return -1;
+  }
+  // Vmengine/fquery.c:440-446
+  if (searchlength < index->pl)
+  {
+    VSA_ERROR("searchlength=%lu must be >= %lu=prefixlen",
+              (unsigned long) searchlength, (unsigned long) index->pl);
+    return -2;
+  }
+  if (searchlength > 0xFFFFFFFFull || queries->maxlength > 0xFFFFFFF0ull)
+  {
+    VSA_ERROR("query or search length beyond 32 bits is not supported");
+    return -3;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const bool mum = domaximaluniquematch != 0,
+             cand = domaximaluniquematchcandidates != 0;
+  const int rc =
+      (index->isize == 4)
+          ? run_query<uint32_t>(index, queries, mum, cand,
+                                (uint32_t) searchlength, res)
+          : run_query<uint64_t>(index, queries, mum, cand,
+                                (uint32_t) searchlength, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
+}
+
+extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,
+                                            uint64_t searchlength,
+                                            vsa_result **result)
+{
+  if (index == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findmaximaluniquematches: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  // Vmengine/fmumself.c:21-31
+  if (!index->hasindexedqueries)
+  {
+    VSA_ERROR("maximal unique matches search requires at least one query "
+              "file");
+    return -1;
+  }
+  if (index->n < 2)
+  {
+    VSA_ERROR("search for maximal unique matches requires at least a table "
+              "of length 2");
+    return -2;
+  }
+  if (index->bwt == nullptr)
+  {
+    VSA_ERROR("table bwt is not loaded");
+    return -3;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc = (index->isize == 4)
+                     ? run_selfmum<uint32_t>(index, searchlength, res)
+                     : run_selfmum<uint64_t>(index, searchlength, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
+}

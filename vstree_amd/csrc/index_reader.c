@@ -1,0 +1,337 @@
+/*
+  Reader for the on-disk index mkvtree writes (host side, plain C).
+
+  Stands in for mapvirtualtreeifyoucan (kurtz-basic/readvirt.c:776-907) with
+  the demand vmatch computes for this path, TISTAB|SUFTAB|LCPTAB|BCKTAB
+  (+BWTTAB for the self-MUM scan), Vmatch/mapdemand.c:100-210, and for the
+  project-file parser kurtz-basic/multiseq-adv.c:1719-1918.  Files are raw
+  host-endian arrays without headers (Mkvtree/mkvprocess.c:99-816):
+
+    IDX.prj  key=value text: totallength, prefixlength, largelcpvalues,
+             integersize (32|64), littleendian, numofdbsequences, ...
+    IDX.al1  symbol map, one class per line, last line = wildcard class
+    IDX.tis  uchar[n]      IDX.suf  Uint[n+1]     IDX.lcp  uchar[n+1]
+    IDX.llv  Uint[2*largelcpvalues]               IDX.bck  Uint[2*k^pl]
+    IDX.bwt  uchar[n+1]    IDX.ssp  Uint[numofsequences-1]
+
+  Like the reference (readvirt.c:111-122) every table is mmap'ed read-only
+  and its size is checked against the expected one; unlike it both integer
+  sizes are accepted whatever the word size of this build.
+*/
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include "vstree_amd.h"
+
+char *vsa_errbuf(void);
+#define ERRSIZE 1024
+
+typedef struct
+{
+  void *ptr;
+  size_t size;
+} Mapped;
+
+static int mapfile(const char *indexname, const char *suffix,
+                   uint64_t expected, int required, Mapped *m)
+{
+  char path[4096 + 32];
+  struct stat st;
+  int fd;
+
+  m->ptr = NULL;
+  m->size = 0;
+  snprintf(path, sizeof path, "%s.%s", indexname, suffix);
+  fd = open(path, O_RDONLY);
+  if (fd < 0)
+  {
+    if (!required)
+    {
+      return 1;
+    }
+    snprintf(vsa_errbuf(), ERRSIZE, "cannot open \"%s\": %s", path,
+             strerror(errno));
+    return -1;
+  }
+  if (fstat(fd, &st) != 0)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE, "cannot stat \"%s\": %s", path,
+             strerror(errno));
+    close(fd);
+    return -1;
+  }
+  if ((uint64_t) st.st_size != expected)
+  {
+    /* the reference's EXPECTED check, kurtz-basic/readvirt.c:118-119 */
+    snprintf(vsa_errbuf(), ERRSIZE,
+             "mapping file \"%s\": %lu bytes, expected %lu", path,
+             (unsigned long) st.st_size, (unsigned long) expected);
+    close(fd);
+    return -1;
+  }
+  if (expected > 0)
+  {
+    m->ptr = mmap(NULL, (size_t) expected, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m->ptr == MAP_FAILED)
+    {
+      snprintf(vsa_errbuf(), ERRSIZE, "cannot map \"%s\": %s", path,
+               strerror(errno));
+      m->ptr = NULL;
+      close(fd);
+      return -1;
+    }
+    m->size = (size_t) expected;
+  }
+  close(fd);
+  return 0;
+}
+
+static void unmap(Mapped *m)
+{
+  if (m->ptr != NULL)
+  {
+    munmap(m->ptr, m->size);
+    m->ptr = NULL;
+  }
+}
+
+typedef struct
+{
+  uint64_t totallength, prefixlength, largelcpvalues, integersize,
+           littleendian, numofsequences, numofdbsequences,
+           numofquerysequences;
+  int have_totallength, have_prefixlength, have_integersize,
+      have_littleendian;
+} Prj;
+
+static int readprj(const char *indexname, Prj *prj)
+{
+  char path[4096 + 32], line[8192];
+  FILE *fp;
+
+  memset(prj, 0, sizeof *prj);
+  prj->numofsequences = 1;
+  prj->numofdbsequences = 1;
+  snprintf(path, sizeof path, "%s.prj", indexname);
+  fp = fopen(path, "r");
+  if (fp == NULL)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE, "cannot open \"%s\": %s", path,
+             strerror(errno));
+    return -1;
+  }
+  while (fgets(line, sizeof line, fp) != NULL)
+  {
+    char *eq = strchr(line, '=');
+    unsigned long long v;
+
+    if (eq == NULL)
+    {
+      continue;
+    }
+    *eq = '\0';
+    if (strcmp(line, "dbfile") == 0 || strcmp(line, "queryfile") == 0)
+    {
+      continue;
+    }
+    v = strtoull(eq + 1, NULL, 10);
+#define FIELD(NAME)                                                           \
+  if (strcmp(line, #NAME) == 0)                                               \
+  {                                                                           \
+    prj->NAME = v;                                                            \
+  }
+    FIELD(totallength)
+    FIELD(prefixlength)
+    FIELD(largelcpvalues)
+    FIELD(integersize)
+    FIELD(littleendian)
+    FIELD(numofsequences)
+    FIELD(numofdbsequences)
+    FIELD(numofquerysequences)
+#undef FIELD
+    if (strcmp(line, "totallength") == 0)
+    {
+      prj->have_totallength = 1;
+    }
+    if (strcmp(line, "prefixlength") == 0)
+    {
+      prj->have_prefixlength = 1;
+    }
+    if (strcmp(line, "integersize") == 0)
+    {
+      prj->have_integersize = 1;
+    }
+    if (strcmp(line, "littleendian") == 0)
+    {
+      prj->have_littleendian = 1;
+    }
+  }
+  fclose(fp);
+  if (!prj->have_totallength || !prj->have_prefixlength)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE,
+             "%s.prj: missing line totallength= or prefixlength=", indexname);
+    return -1;
+  }
+  if (!prj->have_integersize ||
+      (prj->integersize != 32 && prj->integersize != 64))
+  {
+    /* kurtz-basic/multiseq-adv.c:1856-1872 */
+    snprintf(vsa_errbuf(), ERRSIZE,
+             "%s.prj contains illegal line defining the integer size",
+             indexname);
+    return -1;
+  }
+  if (!prj->have_littleendian)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE,
+             "%s.prj contains illegal line defining the endianness",
+             indexname);
+    return -1;
+  }
+  {
+    const uint16_t probe = 1;
+    const int hostlittle = *(const uint8_t *) &probe == 1;
+    if ((prj->littleendian != 0) != hostlittle)
+    {
+      /* kurtz-basic/multiseq-adv.c:1880-1898 */
+      snprintf(vsa_errbuf(), ERRSIZE,
+               "index was built on a computer with %s endian byte order, "
+               "this computer has %s endian byte order",
+               prj->littleendian ? "little" : "big",
+               hostlittle ? "little" : "big");
+      return -1;
+    }
+  }
+  return 0;
+}
+
+/* number of symbol classes in IDX.al1 minus the wildcard class = the
+   reference's alpha.mapsize - 1 (kurtz-basic/alphabet.c) */
+static int readnumofchars(const char *indexname, uint32_t *numofchars)
+{
+  char path[4096 + 32], line[4096];
+  FILE *fp;
+  uint32_t lines = 0;
+
+  snprintf(path, sizeof path, "%s.al1", indexname);
+  fp = fopen(path, "r");
+  if (fp == NULL)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE, "cannot open \"%s\": %s", path,
+             strerror(errno));
+    return -1;
+  }
+  while (fgets(line, sizeof line, fp) != NULL)
+  {
+    if (line[0] != '\n' && line[0] != '\0')
+    {
+      lines++;
+    }
+  }
+  fclose(fp);
+  if (lines < 2)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE, "\"%s\": not a symbol map", path);
+    return -1;
+  }
+  *numofchars = lines - 1;
+  return 0;
+}
+
+int vsa_index_open(const char *indexname, int device, vsa_index **index)
+{
+  Prj prj;
+  Mapped tis, suf, lcp, llv, bck, bwt, ssp;
+  vsa_tables t;
+  uint32_t numofchars = 0, k;
+  uint64_t numofcodes = 1, w;
+  int rc = -1, have_bwt;
+
+  if (indexname == NULL || index == NULL)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE, "vsa_index_open: NULL argument");
+    return -1;
+  }
+  *index = NULL;
+  if (readprj(indexname, &prj) != 0 ||
+      readnumofchars(indexname, &numofchars) != 0)
+  {
+    return -1;
+  }
+  if (prj.prefixlength == 0 || prj.prefixlength > 32)
+  {
+    snprintf(vsa_errbuf(), ERRSIZE,
+             "%s.prj: prefixlength=%lu: index has no usable bucket table",
+             indexname, (unsigned long) prj.prefixlength);
+    return -1;
+  }
+  for (k = 0; k < prj.prefixlength; k++)
+  {
+    numofcodes *= numofchars;
+  }
+  w = prj.integersize / 8;
+  memset(&tis, 0, sizeof tis);
+  suf = lcp = llv = bck = bwt = ssp = tis;
+  if (mapfile(indexname, "tis", prj.totallength, 1, &tis) != 0 ||
+      mapfile(indexname, "suf", (prj.totallength + 1) * w, 1, &suf) != 0 ||
+      mapfile(indexname, "lcp", prj.totallength + 1, 1, &lcp) != 0 ||
+      mapfile(indexname, "llv", 2 * prj.largelcpvalues * w, 1, &llv) != 0 ||
+      mapfile(indexname, "bck", 2 * numofcodes * w, 1, &bck) != 0)
+  {
+    goto done;
+  }
+  have_bwt = mapfile(indexname, "bwt", prj.totallength + 1, 0, &bwt);
+  if (have_bwt < 0)
+  {
+    goto done;
+  }
+  memset(&t, 0, sizeof t);
+  t.totallength = prj.totallength;
+  t.prefixlength = (uint32_t) prj.prefixlength;
+  t.numofchars = numofchars;
+  t.integersize = (uint32_t) prj.integersize;
+  t.largelcpvalues = prj.largelcpvalues;
+  t.tis = (const uint8_t *) tis.ptr;
+  t.suf = suf.ptr;
+  t.lcp = (const uint8_t *) lcp.ptr;
+  t.llv = llv.ptr;
+  t.bck = bck.ptr;
+  t.bwt = (have_bwt == 0) ? (const uint8_t *) bwt.ptr : NULL;
+  if (prj.numofquerysequences > 0)
+  {
+    /* separator in front of the first query sequence = ssp[numofdb-1]
+       (getqueryseppos, kurtz-basic/multiseq-adv.c:1005-1018) */
+    if (mapfile(indexname, "ssp", (prj.numofsequences - 1) * w, 1, &ssp) != 0)
+    {
+      goto done;
+    }
+    if (prj.numofdbsequences == 0 ||
+        prj.numofdbsequences > prj.numofsequences - 1)
+    {
+      snprintf(vsa_errbuf(), ERRSIZE, "%s.prj: inconsistent number of "
+               "sequences", indexname);
+      goto done;
+    }
+    t.querysepposition =
+        (w == 8) ? ((const uint64_t *) ssp.ptr)[prj.numofdbsequences - 1]
+                 : ((const uint32_t *) ssp.ptr)[prj.numofdbsequences - 1];
+    t.hasindexedqueries = 1;
+  }
+  rc = vsa_index_from_tables(&t, device, index);
+done:
+  unmap(&tis);
+  unmap(&suf);
+  unmap(&lcp);
+  unmap(&llv);
+  unmap(&bck);
+  unmap(&bwt);
+  unmap(&ssp);
+  return rc;
+}

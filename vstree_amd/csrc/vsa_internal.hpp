@@ -1,0 +1,144 @@
+// Internal declarations shared by the HIP translation units of
+// libvstree_amd.so.  The public C ABI is include/vstree_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "vstree_amd.h"
+
+// ---- error plumbing: one message buffer like the reference's messagespace()
+// (include/errordef.h:13), thread local because the library may be used from
+// one thread per GPU.
+extern "C" char *vsa_errbuf();
+#define VSA_ERRBUF_SIZE 1024
+#define VSA_ERROR(...)                                                        \
+  do                                                                          \
+  {                                                                           \
+    snprintf(vsa_errbuf(), VSA_ERRBUF_SIZE, __VA_ARGS__);                     \
+  } while (0)
+
+#define VSA_HIP(call)                                                         \
+  do                                                                          \
+  {                                                                           \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess)                                                     \
+    {                                                                         \
+      VSA_ERROR("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,            \
+                hipGetErrorString(e_));                                       \
+      return -100;                                                            \
+    }                                                                         \
+  } while (0)
+
+// Bytes in front of / behind the text on the device.  In front: tis[-1] may
+// be loaded as part of an 8-byte word.  Behind: every suffix comparison stops
+// at the first special symbol, and position totallength.. holds 0xFF, which
+// reproduces "sptr >= sentinel => retcode = -1" (kurtz/maxpref.c:57-61)
+// without a bounds test; 8-byte loads may run 7 bytes past it.
+#define VSA_TIS_FRONTPAD 16
+#define VSA_TIS_BACKPAD 32
+// queries are compared 8 bytes at a time, too
+#define VSA_QUERY_BACKPAD 16
+
+// Device view of one index; IDX = uint32_t while totallength+1 fits, else
+// uint64_t.  Passed to kernels by value.
+template <typename IDX>
+struct DevIndex
+{
+  const uint8_t *tis; // [-FRONTPAD, n + BACKPAD)
+  const IDX *suf;     // [n+1]
+  const uint8_t *lcp; // [n+1]
+  const IDX *llv;     // [2*nllv]
+  const IDX *bck;     // [2*numofcodes]
+  const uint8_t *bwt; // [n+1] or nullptr
+  uint64_t n, nllv, numofcodes;
+  uint32_t pl, numofchars;
+};
+
+struct vsa_index
+{
+  int device;
+  hipStream_t stream;
+  uint32_t isize; // bytes per suf/bck/llv entry on the device: 4 or 8
+  uint64_t n, nllv, numofcodes;
+  uint32_t pl, numofchars;
+  uint8_t *tis_alloc; // allocation; text starts at tis_alloc + FRONTPAD
+  void *suf, *llv, *bck;
+  uint8_t *lcp, *bwt;
+  uint64_t querysepposition;
+  int hasindexedqueries;
+  uint64_t device_bytes;
+
+  template <typename IDX>
+  DevIndex<IDX> view() const
+  {
+    DevIndex<IDX> v;
+    v.tis = tis_alloc + VSA_TIS_FRONTPAD;
+    v.suf = (const IDX *) suf;
+    v.lcp = lcp;
+    v.llv = (const IDX *) llv;
+    v.bck = (const IDX *) bck;
+    v.bwt = bwt;
+    v.n = n;
+    v.nllv = nllv;
+    v.numofcodes = numofcodes;
+    v.pl = pl;
+    v.numofchars = numofchars;
+    return v;
+  }
+};
+
+struct vsa_queries
+{
+  int device;
+  uint64_t nq, nsymbols;
+  uint8_t *symbols; // device, nsymbols + VSA_QUERY_BACKPAD
+  uint64_t *start;  // device [nq]
+  uint64_t *length; // device [nq]
+  // host copies of the lengths' summary, for validation without a sync
+  uint64_t minlength, maxlength;
+  uint64_t firstshort_valid; // unused marker
+  std::vector<uint64_t> hlength; // host copy (needed for ragged batches)
+  bool uniform;                  // all lengths equal
+};
+
+struct vsa_result
+{
+  int device;
+  uint64_t count;
+  vsa_match *matches; // device
+  vsa_stats stats;
+};
+
+// device-side view of a query batch
+struct DevQueries
+{
+  const uint8_t *symbols;
+  const uint64_t *start;
+  const uint64_t *length;
+  uint64_t nq;
+  uint32_t uniformlen; // != 0: every query has this length
+};
+
+static inline DevQueries devqueries(const vsa_queries *q)
+{
+  DevQueries d;
+  d.symbols = q->symbols;
+  d.start = q->start;
+  d.length = q->length;
+  d.nq = q->nq;
+  d.uniformlen = (q->uniform && q->maxlength < 0xFFFFFFFFull)
+                     ? (uint32_t) q->maxlength
+                     : 0;
+  return d;
+}
+
+int vsa_set_device(int device);
+
+// device tables of the given shape, contents undefined (api.hip)
+int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
+                    uint64_t nllv, bool withbwt, int device, vsa_index **out);
+
