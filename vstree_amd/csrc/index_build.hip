@@ -1,16 +1,819 @@
-// GPU construction of the index tables (placeholder until the builder lands)
-#include "vsa_internal.hpp"
+// GPU construction of the enhanced suffix array mkvtree writes
+// (tis -> suf, lcp + llv, bck, bwt), byte-identical to the reference's tables
+// (definitions: Mkvtree/bese.c:27-49,533-566,602, Mkvtree/mkvprocess.c:251-400,
+// kurtz/bwtcode.c:293-311).  The reference sorts with a bucket sort plus
+// Bentley-Sedgewick multikey quicksort on one core (Mkvtree/ppsort.c:83,
+// Mkvtree/bese.c:710); this builder is designed for the GPU instead:
+//
+//   B1  k_pack_keys      key(i) = first H symbols of suffix i, 3 (or more)
+//                        bits each, specials and everything behind them
+//                        masked: one streaming pass over the text
+//   B2  rocPRIM radix sort of (key, i): stable, so suffixes that run into a
+//                        special symbol inside H symbols are already in
+//                        their final order (specials are unique symbols
+//                        ordered by text position)
+//   B3  prefix doubling (Larsson-Sadakane) only on the groups that are still
+//                        tied: rank of suffix i+h as second key, h = H, 2H, ...
+//   B4  k_lcp_chunks     Kasai's lcp(i+1) >= lcp(i)-1 inside chunks of
+//                        consecutive text positions, one work-item per chunk,
+//                        8 symbols per comparison; values >= 255 go to llv
+//   B5  k_bck_*          bucket boundaries (left, mid) from the sorted order
+//   B6  k_bwt            bwt[j] = tis[suf[j]-1]
+//
+// Limited to totallength + 1 < 2^32 in this round (32-bit suf on the device).
+#include <cstring>
+#include <algorithm>
+#include <cmath>
+#include "esa_device.hpp"
+#include <rocprim/rocprim.hpp>
 
-extern "C" int vsa_index_build(const uint8_t *, uint64_t, uint32_t, uint32_t,
-                               int, vsa_index **)
+#define VB_BLOCK 256
+#define VB_LCP_CHUNK 32
+
+namespace
 {
-  VSA_ERROR("vsa_index_build: not available in this build");
-  return -1;
+
+struct DevBuf
+{
+  void *p = nullptr;
+  ~DevBuf()
+  {
+    if (p != nullptr)
+    {
+      (void) hipFree(p);
+    }
+  }
+  int alloc(size_t bytes)
+  {
+    if (p != nullptr)
+    {
+      (void) hipFree(p);
+      p = nullptr;
+    }
+    VSA_HIP(hipMalloc(&p, bytes > 0 ? bytes : 16));
+    return 0;
+  }
+  void free()
+  {
+    if (p != nullptr)
+    {
+      (void) hipFree(p);
+      p = nullptr;
+    }
+  }
+  template <typename T>
+  T *as()
+  {
+    return (T *) p;
+  }
+};
+
+inline unsigned int gridfor(uint64_t items)
+{
+  return (unsigned int) ((items + VB_BLOCK - 1) / VB_BLOCK);
 }
 
-extern "C" int vsa_index_build_device(const void *, uint64_t, uint32_t,
-                                      uint32_t, int, vsa_index **)
+} // namespace
+
+// ---- B1: keys -------------------------------------------------------------
+
+// symbol -> code with `bits` bits: regular c -> c, special -> numofchars.
+// The key holds H = 63/bits (at most) symbols, first symbol most significant;
+// from the first special on everything is zero, and bit 63 is set iff the key
+// contains a special: such keys are unique up to text position.
+__global__ void __launch_bounds__(VB_BLOCK)
+k_pack_keys(const uint8_t *__restrict__ tis, uint64_t n, uint32_t numofchars,
+            uint32_t bits, uint32_t H, uint64_t *__restrict__ keys,
+            uint32_t *__restrict__ sa)
 {
-  VSA_ERROR("vsa_index_build_device: not available in this build");
-  return -1;
+  const uint64_t i = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (i > n)
+  {
+    return;
+  }
+  uint64_t key = 0;
+  bool special = false;
+  // tis is padded with 0xFF from position n on
+  for (uint32_t k = 0; k < H; k++)
+  {
+    uint64_t c = 0;
+    if (!special)
+    {
+      const uint8_t a = tis[i + k];
+      if (VSA_ISSPECIAL(a))
+      {
+        special = true;
+        c = numofchars;
+      } else
+      {
+        c = a;
+      }
+    }
+    key = (key << bits) | c;
+  }
+  keys[i] = key | (special ? (1ull << 63) : 0ull);
+  sa[i] = (uint32_t) i;
+}
+
+// Caution on bit 63: it must not take part in the ORDER (a key with a special
+// at offset j sorts by its symbols, the special code numofchars being the
+// largest symbol); it is only a marker.  The sort runs on bits [0, 63).
+
+// ---- B3: groups -----------------------------------------------------------
+
+// head[j] = j where a new group starts, else 0 (then max-scanned)
+__global__ void __launch_bounds__(VB_BLOCK)
+k_initial_heads(const uint64_t *__restrict__ keys, uint64_t count,
+                uint32_t *__restrict__ head)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j >= count)
+  {
+    return;
+  }
+  const uint64_t k = keys[j];
+  const bool start = (j == 0) || (k >> 63) != 0 || keys[j - 1] != k;
+  head[j] = start ? (uint32_t) j : 0u;
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_scatter_rank(const uint32_t *__restrict__ sa,
+               const uint32_t *__restrict__ head, uint64_t count,
+               uint32_t *__restrict__ isa)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j < count)
+  {
+    isa[sa[j]] = head[j];
+  }
+}
+
+// flag[j] = 1 iff j sits in a group of more than one suffix
+__global__ void __launch_bounds__(VB_BLOCK)
+k_flag_unresolved(const uint32_t *__restrict__ head, uint64_t count,
+                  uint8_t *__restrict__ flag)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j >= count)
+  {
+    return;
+  }
+  const bool tied = head[j] != (uint32_t) j ||
+                    (j + 1 < count && head[j + 1] == (uint32_t) j);
+  flag[j] = tied ? 1 : 0;
+}
+
+// for the tied positions pos[r]: composite key (group head, rank of the
+// suffix h symbols further on) and the suffix itself
+__global__ void __launch_bounds__(VB_BLOCK)
+k_doubling_keys(const uint32_t *__restrict__ pos, uint64_t m,
+                const uint32_t *__restrict__ sa,
+                const uint32_t *__restrict__ head,
+                const uint32_t *__restrict__ isa, uint64_t h, uint64_t n,
+                uint64_t *__restrict__ ckey, uint32_t *__restrict__ csuf)
+{
+  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (r >= m)
+  {
+    return;
+  }
+  const uint32_t j = pos[r];
+  const uint32_t s = sa[j];
+  // tied suffixes share h regular symbols, so s + h <= n
+  const uint64_t next = (uint64_t) s + h;
+  const uint32_t second = isa[next <= n ? next : n];
+  ckey[r] = ((uint64_t) head[j] << 32) | second;
+  csuf[r] = s;
+}
+
+// after sorting the tied suffixes by composite key: new group starts
+__global__ void __launch_bounds__(VB_BLOCK)
+k_doubling_heads(const uint64_t *__restrict__ ckey,
+                 const uint32_t *__restrict__ pos, uint64_t m,
+                 uint32_t *__restrict__ newhead)
+{
+  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (r >= m)
+  {
+    return;
+  }
+  const bool start = (r == 0) || ckey[r - 1] != ckey[r];
+  newhead[r] = start ? pos[r] : 0u;
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_doubling_writeback(const uint32_t *__restrict__ pos,
+                     const uint32_t *__restrict__ csuf,
+                     const uint32_t *__restrict__ newhead, uint64_t m,
+                     uint32_t *__restrict__ sa, uint32_t *__restrict__ head,
+                     uint32_t *__restrict__ isa)
+{
+  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (r >= m)
+  {
+    return;
+  }
+  const uint32_t j = pos[r], s = csuf[r], hd = newhead[r];
+  sa[j] = s;
+  head[j] = hd;
+  isa[s] = hd;
+}
+
+// among the previously tied positions: which are still tied
+__global__ void __launch_bounds__(VB_BLOCK)
+k_doubling_flags(const uint32_t *__restrict__ pos,
+                 const uint32_t *__restrict__ newhead, uint64_t m,
+                 uint8_t *__restrict__ flag)
+{
+  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (r >= m)
+  {
+    return;
+  }
+  const bool tied = newhead[r] != pos[r] ||
+                    (r + 1 < m && newhead[r + 1] == pos[r]);
+  flag[r] = tied ? 1 : 0;
+}
+
+// ---- B4: lcp --------------------------------------------------------------
+
+// number of leading regular symbols two suffixes share, starting the
+// comparison at offset h (8 symbols per step; the text is padded with 0xFF)
+__device__ __forceinline__ uint64_t vb_extend(const uint8_t *__restrict__ tis,
+                                              uint64_t a, uint64_t b,
+                                              uint64_t h)
+{
+  for (;;)
+  {
+    const uint64_t x = vsa_load8(tis + a + h), y = vsa_load8(tis + b + h);
+    const uint64_t m = (x ^ y) | vsa_specialmask(x);
+    if (m != 0)
+    {
+      return h + ((uint32_t) __builtin_ctzll(m) >> 3);
+    }
+    h += 8;
+  }
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_lcp_chunks(const uint8_t *__restrict__ tis, uint64_t n,
+             const uint32_t *__restrict__ sa,
+             const uint32_t *__restrict__ isa, uint8_t *__restrict__ lcp,
+             uint32_t *__restrict__ llvidx, uint32_t *__restrict__ llvval,
+             uint64_t llvcap, unsigned long long *__restrict__ llvcount)
+{
+  const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t i0 = c * VB_LCP_CHUNK;
+  if (i0 > n)
+  {
+    return;
+  }
+  const uint64_t i1 = (i0 + VB_LCP_CHUNK <= n + 1) ? i0 + VB_LCP_CHUNK : n + 1;
+  uint64_t h = 0;
+  for (uint64_t i = i0; i < i1; i++)
+  {
+    const uint32_t r = isa[i];
+    if (r == 0)
+    {
+      lcp[0] = 0;
+      h = 0;
+      continue;
+    }
+    const uint32_t j = sa[r - 1];
+    h = vb_extend(tis, i, j, h);
+    if (h < 255)
+    {
+      lcp[r] = (uint8_t) h;
+    } else
+    {
+      lcp[r] = 255;
+      const unsigned long long slot = atomicAdd(llvcount, 1ull);
+      if (slot < llvcap)
+      {
+        llvidx[slot] = r;
+        llvval[slot] = (uint32_t) h;
+      }
+    }
+    if (h > 0)
+    {
+      h--;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_llv_pairs(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ val,
+            uint64_t m, uint32_t *__restrict__ llv)
+{
+  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (r < m)
+  {
+    llv[2 * r] = idx[r];
+    llv[2 * r + 1] = val[r];
+  }
+}
+
+// ---- B5: bck --------------------------------------------------------------
+
+// code of the first pl symbols, a suffix cut short by a special symbol padded
+// with the largest regular symbol: that is where it sorts
+__device__ __forceinline__ uint64_t vb_padcode(const uint8_t *__restrict__ tis,
+                                               uint64_t s, uint32_t pl,
+                                               uint32_t numofchars, bool &cut)
+{
+  uint64_t c = 0;
+  cut = false;
+  for (uint32_t k = 0; k < pl; k++)
+  {
+    uint64_t a = numofchars - 1;
+    if (!cut)
+    {
+      const uint8_t t = tis[s + k];
+      if (VSA_ISSPECIAL(t))
+      {
+        cut = true;
+      } else
+      {
+        a = t;
+      }
+    }
+    c = c * numofchars + a;
+  }
+  return c;
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_bck_init(uint32_t *__restrict__ left, uint32_t *__restrict__ mid,
+           uint64_t numofcodes)
+{
+  const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (c < numofcodes)
+  {
+    left[c] = 0xFFFFFFFFu;
+    mid[c] = 0xFFFFFFFFu;
+  }
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_bck_boundaries(const uint8_t *__restrict__ tis, uint64_t n,
+                 const uint32_t *__restrict__ sa, uint32_t pl,
+                 uint32_t numofchars, uint32_t *__restrict__ left,
+                 uint32_t *__restrict__ mid)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j > n)
+  {
+    return;
+  }
+  bool cut, prevcut = false;
+  const uint64_t code = vb_padcode(tis, sa[j], pl, numofchars, cut);
+  uint64_t prevcode = 0;
+  if (j > 0)
+  {
+    prevcode = vb_padcode(tis, sa[j - 1], pl, numofchars, prevcut);
+  }
+  if (j == 0 || prevcode != code)
+  {
+    left[code] = (uint32_t) j;
+  }
+  if (cut && (j == 0 || prevcode != code || !prevcut))
+  {
+    mid[code] = (uint32_t) j;
+  }
+}
+
+// left[] has been min-scanned from the right: empty buckets start where the
+// next occupied one starts.  A bucket without cut suffixes ends there, too.
+__global__ void __launch_bounds__(VB_BLOCK)
+k_bck_finish(const uint32_t *__restrict__ left,
+             const uint32_t *__restrict__ mid, uint64_t numofcodes,
+             uint32_t *__restrict__ bck)
+{
+  const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (c >= numofcodes)
+  {
+    return;
+  }
+  const uint32_t l = left[c];
+  uint32_t m = mid[c];
+  if (m == 0xFFFFFFFFu)
+  {
+    // the last code always holds the end sentinel as a cut suffix, so c+1
+    // exists whenever mid is unset
+    m = left[c + 1];
+  }
+  bck[2 * c] = l;
+  bck[2 * c + 1] = m;
+}
+
+// ---- B6: bwt --------------------------------------------------------------
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_bwt(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ sa,
+      uint64_t n, uint8_t *__restrict__ bwt)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j <= n)
+  {
+    const uint32_t s = sa[j];
+    bwt[j] = (s > 0) ? tis[s - 1] : (uint8_t) VSA_UNDEFBWT;
+  }
+}
+
+// ---------------------------------------------------------------------------
+
+namespace
+{
+
+// kurtz/detpfxlen.c:31-61 with sizeofbckentry = 16 (include/virtualdef.h:104,
+// 64-bit Uint as in the reference's build)
+uint32_t recommendedprefixlength(uint32_t numofchars, uint64_t totallength)
+{
+  const double value = (double) totallength / 16.0;
+  if (value <= (double) numofchars)
+  {
+    return 1;
+  }
+  const uint32_t pl =
+      (uint32_t) floor(log(value) / log((double) numofchars));
+  return pl == 0 ? 1 : pl;
+}
+
+struct MaxOp
+{
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const
+  {
+    return a > b ? a : b;
+  }
+};
+
+struct MinOp
+{
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const
+  {
+    return a < b ? a : b;
+  }
+};
+
+int maxscan_inplace(uint32_t *data, uint64_t count, hipStream_t stream)
+{
+  DevBuf temp;
+  size_t tb = 0;
+  VSA_HIP(rocprim::inclusive_scan(nullptr, tb, data, data, (size_t) count,
+                                  MaxOp(), stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::inclusive_scan(temp.p, tb, data, data, (size_t) count,
+                                  MaxOp(), stream));
+  return 0;
+}
+
+int build_tables(vsa_index *ix)
+{
+  hipStream_t stream = ix->stream;
+  const uint64_t n = ix->n, count = n + 1;
+  const uint8_t *tis = ix->tis_alloc + VSA_TIS_FRONTPAD;
+  uint32_t *sa = (uint32_t *) ix->suf;
+  uint32_t bits = 1;
+  while ((1u << bits) < ix->numofchars + 1)
+  {
+    bits++;
+  }
+  const uint32_t H = 63 / bits;
+  DevBuf isa, head;
+
+  // B1 + B2
+  {
+    DevBuf keys, keys2, sa2, temp;
+    if (keys.alloc(count * 8) || keys2.alloc(count * 8) ||
+        sa2.alloc(count * 4))
+    {
+      return -100;
+    }
+    k_pack_keys<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+        tis, n, ix->numofchars, bits, H, keys.as<uint64_t>(),
+        sa2.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+    size_t tb = 0;
+    VSA_HIP(rocprim::radix_sort_pairs(
+        nullptr, tb, keys.as<uint64_t>(), keys2.as<uint64_t>(),
+        sa2.as<uint32_t>(), sa, (size_t) count, 0u, H * bits, stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::radix_sort_pairs(
+        temp.p, tb, keys.as<uint64_t>(), keys2.as<uint64_t>(),
+        sa2.as<uint32_t>(), sa, (size_t) count, 0u, H * bits, stream));
+    temp.free();
+    keys.free();
+    sa2.free();
+    if (isa.alloc(count * 4) || head.alloc(count * 4))
+    {
+      return -100;
+    }
+    k_initial_heads<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+        keys2.as<uint64_t>(), count, head.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+  }
+  if (maxscan_inplace(head.as<uint32_t>(), count, stream))
+  {
+    return -100;
+  }
+  k_scatter_rank<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+      sa, head.as<uint32_t>(), count, isa.as<uint32_t>());
+  VSA_HIP(hipGetLastError());
+
+  // B3: positions still tied, refined until none is left
+  {
+    DevBuf flag, pos, dcount, temp, iota;
+    uint64_t m = 0;
+    if (flag.alloc(count) || dcount.alloc(8))
+    {
+      return -100;
+    }
+    k_flag_unresolved<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+        head.as<uint32_t>(), count, flag.as<uint8_t>());
+    VSA_HIP(hipGetLastError());
+    if (pos.alloc(count * 4))
+    {
+      return -100;
+    }
+    {
+      size_t tb = 0;
+      auto counting = rocprim::counting_iterator<uint32_t>(0);
+      VSA_HIP(rocprim::select(nullptr, tb, counting, flag.as<uint8_t>(),
+                              pos.as<uint32_t>(), dcount.as<uint64_t>(),
+                              (size_t) count, stream));
+      if (temp.alloc(tb))
+      {
+        return -100;
+      }
+      VSA_HIP(rocprim::select(temp.p, tb, counting, flag.as<uint8_t>(),
+                              pos.as<uint32_t>(), dcount.as<uint64_t>(),
+                              (size_t) count, stream));
+      VSA_HIP(hipMemcpyAsync(&m, dcount.p, 8, hipMemcpyDeviceToHost, stream));
+      VSA_HIP(hipStreamSynchronize(stream));
+    }
+    flag.free();
+    uint64_t h = H;
+    while (m > 0)
+    {
+      DevBuf ckey, ckey2, csuf, csuf2, newhead, rflag, pos2, t2;
+      if (ckey.alloc(m * 8) || ckey2.alloc(m * 8) || csuf.alloc(m * 4) ||
+          csuf2.alloc(m * 4) || newhead.alloc(m * 4) || rflag.alloc(m) ||
+          pos2.alloc(m * 4))
+      {
+        return -100;
+      }
+      k_doubling_keys<<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          pos.as<uint32_t>(), m, sa, head.as<uint32_t>(), isa.as<uint32_t>(),
+          h, n, ckey.as<uint64_t>(), csuf.as<uint32_t>());
+      VSA_HIP(hipGetLastError());
+      size_t tb = 0;
+      VSA_HIP(rocprim::radix_sort_pairs(
+          nullptr, tb, ckey.as<uint64_t>(), ckey2.as<uint64_t>(),
+          csuf.as<uint32_t>(), csuf2.as<uint32_t>(), (size_t) m, 0u, 64u,
+          stream));
+      if (t2.alloc(tb))
+      {
+        return -100;
+      }
+      VSA_HIP(rocprim::radix_sort_pairs(
+          t2.p, tb, ckey.as<uint64_t>(), ckey2.as<uint64_t>(),
+          csuf.as<uint32_t>(), csuf2.as<uint32_t>(), (size_t) m, 0u, 64u,
+          stream));
+      k_doubling_heads<<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          ckey2.as<uint64_t>(), pos.as<uint32_t>(), m,
+          newhead.as<uint32_t>());
+      VSA_HIP(hipGetLastError());
+      if (maxscan_inplace(newhead.as<uint32_t>(), m, stream))
+      {
+        return -100;
+      }
+      k_doubling_writeback<<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          pos.as<uint32_t>(), csuf2.as<uint32_t>(), newhead.as<uint32_t>(), m,
+          sa, head.as<uint32_t>(), isa.as<uint32_t>());
+      VSA_HIP(hipGetLastError());
+      k_doubling_flags<<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          pos.as<uint32_t>(), newhead.as<uint32_t>(), m,
+          rflag.as<uint8_t>());
+      VSA_HIP(hipGetLastError());
+      uint64_t m2 = 0;
+      tb = 0;
+      VSA_HIP(rocprim::select(nullptr, tb, pos.as<uint32_t>(),
+                              rflag.as<uint8_t>(), pos2.as<uint32_t>(),
+                              dcount.as<uint64_t>(), (size_t) m, stream));
+      if (t2.alloc(tb))
+      {
+        return -100;
+      }
+      VSA_HIP(rocprim::select(t2.p, tb, pos.as<uint32_t>(),
+                              rflag.as<uint8_t>(), pos2.as<uint32_t>(),
+                              dcount.as<uint64_t>(), (size_t) m, stream));
+      VSA_HIP(hipMemcpyAsync(&m2, dcount.p, 8, hipMemcpyDeviceToHost,
+                             stream));
+      VSA_HIP(hipStreamSynchronize(stream));
+      if (m2 > 0)
+      {
+        VSA_HIP(hipMemcpyAsync(pos.p, pos2.p, m2 * 4,
+                               hipMemcpyDeviceToDevice, stream));
+        VSA_HIP(hipStreamSynchronize(stream));
+      }
+      m = m2;
+      h *= 2;
+      if (h > 2 * count + 2 * H && m > 0)
+      {
+        VSA_ERROR("suffix sorting did not converge");
+        return -6;
+      }
+    }
+  }
+  head.free();
+
+  // B4: lcp + exceptions
+  {
+    DevBuf llvidx, llvval, cnt, sidx, sval, temp;
+    uint64_t llvcap = 1 << 20, needed = 0;
+    if (cnt.alloc(8))
+    {
+      return -100;
+    }
+    for (int attempt = 0; attempt < 2; attempt++)
+    {
+      if (llvidx.alloc(llvcap * 4) || llvval.alloc(llvcap * 4))
+      {
+        return -100;
+      }
+      VSA_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
+      const uint64_t chunks = (count + VB_LCP_CHUNK - 1) / VB_LCP_CHUNK;
+      k_lcp_chunks<<<gridfor(chunks), VB_BLOCK, 0, stream>>>(
+          tis, n, sa, isa.as<uint32_t>(), ix->lcp, llvidx.as<uint32_t>(),
+          llvval.as<uint32_t>(), llvcap,
+          cnt.as<unsigned long long>());
+      VSA_HIP(hipGetLastError());
+      VSA_HIP(hipMemcpyAsync(&needed, cnt.p, 8, hipMemcpyDeviceToHost,
+                             stream));
+      VSA_HIP(hipStreamSynchronize(stream));
+      if (needed <= llvcap)
+      {
+        break;
+      }
+      llvcap = needed;
+    }
+    isa.free();
+    ix->nllv = needed;
+    (void) hipFree(ix->llv);
+    ix->llv = nullptr;
+    VSA_HIP(hipMalloc(&ix->llv, 2 * needed * 4 + 16));
+    ix->device_bytes += 2 * needed * 4;
+    if (needed > 0)
+    {
+      // exceptions sorted by index (Mkvtree/bese.c:557-566 emits them so)
+      if (sidx.alloc(needed * 4) || sval.alloc(needed * 4))
+      {
+        return -100;
+      }
+      size_t tb = 0;
+      VSA_HIP(rocprim::radix_sort_pairs(
+          nullptr, tb, llvidx.as<uint32_t>(), sidx.as<uint32_t>(),
+          llvval.as<uint32_t>(), sval.as<uint32_t>(), (size_t) needed, 0u,
+          32u, stream));
+      if (temp.alloc(tb))
+      {
+        return -100;
+      }
+      VSA_HIP(rocprim::radix_sort_pairs(
+          temp.p, tb, llvidx.as<uint32_t>(), sidx.as<uint32_t>(),
+          llvval.as<uint32_t>(), sval.as<uint32_t>(), (size_t) needed, 0u,
+          32u, stream));
+      k_llv_pairs<<<gridfor(needed), VB_BLOCK, 0, stream>>>(
+          sidx.as<uint32_t>(), sval.as<uint32_t>(), needed,
+          (uint32_t *) ix->llv);
+      VSA_HIP(hipGetLastError());
+      VSA_HIP(hipStreamSynchronize(stream));
+    }
+  }
+
+  // B5: bck
+  {
+    DevBuf left, mid, temp;
+    const uint64_t nc = ix->numofcodes;
+    if (left.alloc((nc + 1) * 4) || mid.alloc(nc * 4))
+    {
+      return -100;
+    }
+    k_bck_init<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
+        left.as<uint32_t>(), mid.as<uint32_t>(), nc);
+    VSA_HIP(hipGetLastError());
+    k_bck_boundaries<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+        tis, n, sa, ix->pl, ix->numofchars, left.as<uint32_t>(),
+        mid.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+    // suffix-min over the codes = inclusive min-scan on the reversed array
+    size_t tb = 0;
+    auto rin = rocprim::make_reverse_iterator(left.as<uint32_t>() + nc);
+    VSA_HIP(rocprim::inclusive_scan(nullptr, tb, rin, rin, (size_t) nc,
+                                    MinOp(), stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::inclusive_scan(temp.p, tb, rin, rin, (size_t) nc,
+                                    MinOp(), stream));
+    k_bck_finish<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
+        left.as<uint32_t>(), mid.as<uint32_t>(), nc, (uint32_t *) ix->bck);
+    VSA_HIP(hipGetLastError());
+  }
+
+  // B6: bwt
+  if (ix->bwt != nullptr)
+  {
+    k_bwt<<<gridfor(count), VB_BLOCK, 0, stream>>>(tis, sa, n, ix->bwt);
+    VSA_HIP(hipGetLastError());
+  }
+  VSA_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int build_common(const void *src, bool srcondevice, uint64_t totallength,
+                 uint32_t numofchars, uint32_t prefixlength, int device,
+                 vsa_index **index)
+{
+  if (index == nullptr || (src == nullptr && totallength > 0))
+  {
+    VSA_ERROR("vsa_index_build: NULL argument");
+    return -1;
+  }
+  *index = nullptr;
+  if (numofchars == 0 || numofchars > 253)
+  {
+    VSA_ERROR("numofchars=%u is not a usable alphabet size", numofchars);
+    return -2;
+  }
+  if (totallength + 1 >= 0xFFFFFFFFull)
+  {
+    VSA_ERROR("totallength=%lu: the GPU index builder handles texts below "
+              "2^32 symbols", (unsigned long) totallength);
+    return -3;
+  }
+  if (prefixlength == 0)
+  {
+    prefixlength = recommendedprefixlength(numofchars, totallength);
+  }
+  if (pow((double) numofchars, (double) prefixlength) > 4.0e9)
+  {
+    VSA_ERROR("prefixlength=%u is too large for alphabet size %u",
+              prefixlength, numofchars);
+    return -4;
+  }
+  vsa_index *ix = nullptr;
+  int rc = vsa_index_alloc(totallength, prefixlength, numofchars, 0, true,
+                           device, &ix);
+  if (rc != 0)
+  {
+    vsa_index_close(ix);
+    return rc;
+  }
+  if (totallength > 0)
+  {
+    if (hipMemcpy(ix->tis_alloc + VSA_TIS_FRONTPAD, src, totallength,
+                  srcondevice ? hipMemcpyDeviceToDevice
+                              : hipMemcpyHostToDevice) != hipSuccess)
+    {
+      VSA_ERROR("copy of the text failed");
+      vsa_index_close(ix);
+      return -100;
+    }
+  }
+  rc = build_tables(ix);
+  if (rc != 0)
+  {
+    vsa_index_close(ix);
+    return rc;
+  }
+  *index = ix;
+  return 0;
+}
+
+} // namespace
+
+extern "C" int vsa_index_build(const uint8_t *tis, uint64_t totallength,
+                               uint32_t numofchars, uint32_t prefixlength,
+                               int device, vsa_index **index)
+{
+  return build_common(tis, false, totallength, numofchars, prefixlength,
+                      device, index);
+}
+
+extern "C" int vsa_index_build_device(const void *device_tis,
+                                      uint64_t totallength,
+                                      uint32_t numofchars,
+                                      uint32_t prefixlength, int device,
+                                      vsa_index **index)
+{
+  return build_common(device_tis, true, totallength, numofchars,
+                      prefixlength, device, index);
 }
