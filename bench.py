@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native Vmengine query path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, configs[2]): a 3 Gbp synthetic DNA index
+resident in HBM, 10 M queries of 100 bp per GPU, `vmatch -mum -l 20 -q`
+semantics (maximal unique matches of every query suffix, global uniqueness
+filter over the queries).  One "step" = one pass of that hot path over the
+whole query batch; inputs (index tables, query symbols) are resident in HBM
+before the timed region, the match list ends up in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the index is
+replicated, every rank owns 10 M queries of a 10*N M query job (weak
+scaling).  Phase 1 (search) needs no communication; the MUM uniqueness filter
+(kurtz/cleanMUMcand.c of the reference) is one global step: candidates are
+all-gathered over RCCL and filtered on rank 0; one RCCL all-reduce sums the
+match counters.
+
+Prints ONE JSON line on rank 0.  Extra objects: "roofline" (dominant kernel
+k_query_search, algorithmic bytes from the instrumented CPU restatement) and
+"cpu_baseline" (rank 0, N = 1: the CPU oracle = port of the reference's
+default algorithm, one core, on a bounded sample of the same batch).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genome", type=float, default=3e9,
+                    help="index length in bp (default 3 Gbp)")
+    ap.add_argument("--queries", type=float, default=1e7,
+                    help="queries per GPU (default 10 M)")
+    ap.add_argument("--qlen", type=int, default=100)
+    ap.add_argument("--minlen", type=int, default=20, help="vmatch -l")
+    ap.add_argument("--cpu-sample", type=int, default=200000,
+                    help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=1)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(H, host_index, sample, minlen, w):
+    """bytes the search has to touch per query, counted by the instrumented
+    CPU restatement running the GPU's algorithm (bucket + binary search per
+    query suffix): per search 2w (bck pair) + probes*w
+    (suf) + compared symbols (tis) + lcp entries; per query its m symbols;
+    per reported match w (suf) + 1 (left symbol) + 32 (record written)."""
+    H.oracle_counters(reset=True)
+    H.oracle_querymatches(host_index, sample, minlen, mum=True, cand=True,
+                          speedup=0)
+    c = H.oracle_counters(reset=True)
+    nq = sample.nq
+    total = (c["bckreads"] * 2 * w + c["sufprobes"] * w + c["charcomp"] +
+             c["lcpreads"] + int(sample.length.sum()) +
+             c["emitted"] * (w + 1 + 32))
+    return total / nq, c
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            log("bench.py: --gpus %d needs torch.distributed.run; running the "
+                "single-process case" % a.gpus)
+        a.gpus = world
+    dev = local_rank
+
+    import vstree_amd as V
+
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    n, nq, m, L = int(a.genome), int(a.queries), a.qlen, a.minlen
+
+    # ---- setup (untimed): genome, index, this rank's queries, all in HBM --
+    t0 = time.time()
+    dg = V.device_malloc(n + 64, dev)
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, n, dg, dev))
+    index = V.Index.build_device(dg, n, 4, 0, dev)
+    t_index = time.time() - t0
+    info = index.info()
+    # rank r owns queries [r*nq, (r+1)*nq) of the world*nq query job
+    pos, sub, step = V.synth_query_plan(n, nq * world, m)
+    sl = slice(rank * nq, (rank + 1) * nq)
+    pos, sub, step = (np.ascontiguousarray(x[sl]) for x in (pos, sub, step))
+    dq = V.device_malloc(nq * m + 64, dev)
+    V._check(V.lib.vsa_synth_queries_device(dg, n, pos.ctypes.data,
+                                            sub.ctypes.data,
+                                            step.ctypes.data, nq, m, dq, dev))
+    queries = V.Queries.from_device(dq, nq, m, dev)
+    queries.set_offset(rank * nq)
+    V.device_free(dq, dev)
+    V.device_free(dg, dev)
+    if rank == 0:
+        log("setup: index %d bp (prefixlength %d, %.1f GB in HBM) built in "
+            "%.1fs, %d queries/GPU" % (n, info.prefixlength,
+                                       info.device_bytes / 1e9, t_index, nq))
+
+    def sync():
+        V.device_synchronize(dev)
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kernel_ms, totals = [], None
+
+    def one_step():
+        """the hot path over the whole batch; returns (count, sumlength,
+        searches, candidates) of the job"""
+        nonlocal totals
+        if world == 1:
+            r = V.findquerymatches(index, queries, L, mum=True)
+            s = r.stats()
+            kernel_ms.append(s.search_kernel_ms)
+            totals = (s.count, s.sumlength, s.searches, s.candidates)
+            r.close()
+            return
+        # phase 1: candidates of this rank's queries (no communication)
+        r = V.findquerymatches(index, queries, L, mum=True, cand=True)
+        s = r.stats()
+        kernel_ms.append(s.search_kernel_ms)
+        ncand = r.count
+        counts = torch.tensor([ncand], dtype=torch.int64, device="cuda")
+        allcounts = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(allcounts, counts)
+        allcounts = [int(c.item()) for c in allcounts]
+        cap = max(allcounts)
+        mine = torch.zeros(cap * 4, dtype=torch.int64, device="cuda")
+        r.copy_device(C.c_void_p(mine.data_ptr()), ncand)
+        r.close()
+        # phase 2: the one exchange step -- candidates to every rank over
+        # RCCL, uniqueness filter on rank 0
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        nmum = sumlen = 0
+        if rank == 0:
+            allc = torch.cat([g[:c * 4] for g, c in zip(gathered, allcounts)])
+            res = V.mumuniqueinquery(C.c_void_p(allc.data_ptr()),
+                                     sum(allcounts), dev)
+            st = res.stats()
+            nmum, sumlen = st.count, st.sumlength
+            res.close()
+        # final reduction of the match counters
+        red = torch.tensor([nmum, sumlen, s.searches, ncand],
+                           dtype=torch.int64, device="cuda")
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        totals = tuple(int(x) for x in red.tolist())
+
+    for _ in range(a.warmup):
+        one_step()
+    kernel_ms.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+
+    count, sumlength, searches, candidates = totals
+    total_queries = nq * world
+    qps = total_queries * a.steps / elapsed
+    kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+
+    out = {
+        "metric": "queries/sec (100 bp queries, vmatch -mum -l 20 "
+                  "semantics, 3 Gbp ESA index resident in HBM)",
+        "value": qps, "unit": "queries/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "3 Gbp synthetic DNA index, 10 M x 100 bp "
+                               "queries per GPU, -mum -l 20 "
+                               "(BASELINE.json configs[2]; configs[3] "
+                               "sharding for N > 1)",
+                   "index_bp": n, "queries_per_gpu": nq, "query_len": m,
+                   "minlen": L, "prefixlength": info.prefixlength,
+                   "index_bytes_hbm": info.device_bytes,
+                   "index_build_s": round(t_index, 2),
+                   "parallelism": "index replicated, queries sharded x%d"
+                                  % world},
+        "gbp_matched_per_s": sumlength * a.steps / elapsed / 1e9
+        if world == 1 else sumlength / (elapsed / a.steps) / 1e9,
+        "matches": count, "candidates": candidates,
+        "query_suffix_searches": searches,
+    }
+
+    if rank == 0:
+        import helpers as H  # test infrastructure: the CPU oracle
+        w = info.device_integersize // 8
+        t = index.download()
+        host = H.Index(n, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
+                       t["llv"], t["bck"], t["bwt"], None)
+        qsym = np.zeros(min(nq, max(a.cpu_sample, 20000)) * m, np.uint8)
+        g = t["tis"]
+        ns = qsym.shape[0] // m
+        for i in range(ns):   # the same queries the GPU has, from the plan
+            p = int(pos[i])
+            qsym[i * m:(i + 1) * m] = g[p:p + m]
+            if sub[i] != V.NO_SUBST:
+                k = i * m + int(sub[i])
+                qsym[k] = (qsym[k] + step[i]) & 3
+        small = H.Queries.uniform(qsym[:20000 * m], m)
+        bytes_per_query, counters = algorithmic_bytes(H, host, small, L, w)
+        alg_bytes_launch = bytes_per_query * nq
+        achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if (tj.get("index_bp") == n and tj.get("queries") == nq):
+                traffic = tj.get("hbm_bytes_per_launch")
+        out["roofline"] = {
+            "kernel": "k_query_search<uint32_t, true>", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel_ms": kms, "algorithmic_bytes_per_query": bytes_per_query,
+            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "note": "random-access bound: every query suffix is a chain of "
+                    "dependent reads into suf/tis/lcp; see DESIGN.md"}
+        if world == 1 and a.cpu_sample > 0:
+            host.sti1 = index.make_sti1()
+            sample = H.Queries.uniform(qsym[:a.cpu_sample * m], m)
+            t0 = time.perf_counter()
+            ref = H.oracle_querymatches(host, sample, L, mum=True, speedup=2)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": sample.nq / dt, "unit": "queries/s", "cores": 1,
+                "kind": "port",
+                "sample": "first %d queries of the same batch, same 3 Gbp "
+                          "index (32-bit tables), oracle/vsoracle.c "
+                          "algorithm 2 = the reference's default -qspeedup 2 "
+                          "incl. the MUM filter, %.1f s, %d MUMs"
+                          % (sample.nq, dt, len(ref))}
+            out["speedup_vs_cpu_1core"] = qps / (sample.nq / dt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

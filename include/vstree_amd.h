@@ -109,6 +109,11 @@ int vsa_index_build_device(const void *device_tis, uint64_t totallength,
                            uint32_t numofchars, uint32_t prefixlength,
                            int device, vsa_index **index);
 
+/* table sti1 of mkvtree (Mkvtree/mkvprocess.c:583-612), computed on the GPU
+   from suf and lcp into host memory sti1[totallength+1]; the GPU search does
+   not use it, the reference's default algorithm (kurtz/matchsub.c:353) does */
+int vsa_index_make_sti1(const vsa_index *index, uint8_t *sti1);
+
 /* copies the device tables back to host buffers sized by the caller from
    vsa_index_getinfo (entries of suf/bck/llv have device_integersize bits);
    NULL pointers are skipped */
@@ -135,6 +140,12 @@ int vsa_queries_from_device(const void *device_symbols, uint64_t nq,
                             uint32_t m, int device, vsa_queries **queries);
 
 void vsa_queries_free(vsa_queries *queries);
+
+/* queryseq of every match = index in the batch + offset: a rank that holds
+   queries [offset, offset+nq) of a larger job reports global numbers
+   (the reference's onlinequerynumoffset, Vmengine/fquery.c:1010,
+   Vmengine/initmstate.c:7-45) */
+int vsa_queries_set_offset(vsa_queries *queries, uint64_t offset);
 
 /* ---- matches ---------------------------------------------------------- */
 
@@ -167,6 +178,10 @@ int vsa_result_getstats(const vsa_result *result, vsa_stats *stats);
 int vsa_result_fetch(const vsa_result *result, vsa_match *matches,
                      uint64_t capacity);
 const void *vsa_result_device_matches(const vsa_result *result);
+/* device-to-device copy of min(count, capacity) matches into caller memory
+   (e.g. a torch tensor that then goes through an RCCL collective) */
+int vsa_result_copy_device(const vsa_result *result, void *device_matches,
+                           uint64_t capacity);
 void vsa_result_free(vsa_result *result);
 
 /* ---- the engine: Vmengine/vmengineexport.h:4-81 ----------------------- */
@@ -208,6 +223,14 @@ int vsa_findquerymatches(const vsa_index *index, const vsa_queries *queries,
 */
 int vsa_findmaximaluniquematches(const vsa_index *index,
                                  uint64_t searchlength, vsa_result **result);
+
+/*
+  mumuniqueinquery (kurtz/cleanMUMcand.c:55-118) on its own: MUM candidates
+  resident in device memory (any order; e.g. gathered from several GPUs) ->
+  MUMs in ascending dbstart order.  The candidate buffer is reordered.
+*/
+int vsa_mumuniqueinquery(void *device_candidates, uint64_t ncandidates,
+                         int device, vsa_result **result);
 
 /*
   The same three entry points with the reference's delivery model: every
@@ -252,6 +275,7 @@ int vsa_synth_queries_device(const void *device_genome, uint64_t n,
 int vsa_device_malloc(uint64_t bytes, int device, void **ptr);
 int vsa_device_free(void *ptr, int device);
 int vsa_device_count(void);
+int vsa_device_synchronize(int device);
 /* measured device-to-device streaming read rate in GB/s (roofline
    denominator cross-check in bench.py) */
 int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);

@@ -83,11 +83,15 @@ def _load():
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
         "vsa_queries_from_device": (I, [V, U64, U32, I, PP]),
         "vsa_queries_free": (None, [V]),
+        "vsa_queries_set_offset": (I, [V, U64]),
         "vsa_result_count": (U64, [V]),
         "vsa_result_getstats": (I, [V, C.POINTER(Stats)]),
         "vsa_result_fetch": (I, [V, V, U64]),
         "vsa_result_device_matches": (V, [V]),
         "vsa_result_free": (None, [V]),
+        "vsa_result_copy_device": (I, [V, V, U64]),
+        "vsa_mumuniqueinquery": (I, [V, U64, I, PP]),
+        "vsa_index_make_sti1": (I, [V, V]),
         "vsa_findcompletematches": (I, [V, V, PP]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
@@ -103,6 +107,7 @@ def _load():
         "vsa_device_malloc": (I, [U64, I, PP]),
         "vsa_device_free": (I, [V, I]),
         "vsa_device_count": (I, []),
+        "vsa_device_synchronize": (I, [I]),
         "vsa_measure_stream_read": (I, [U64, I, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -198,6 +203,11 @@ class Index:
                                       _ptr(out["bwt"])))
         return out
 
+    def make_sti1(self):
+        out = np.zeros(self.info().totallength + 1, np.uint8)
+        _check(lib.vsa_index_make_sti1(self._h, _ptr(out)))
+        return out
+
     def close(self):
         if self._h:
             lib.vsa_index_close(self._h)
@@ -232,6 +242,9 @@ class Queries:
                                            C.byref(h)))
         return cls(h, nq)
 
+    def set_offset(self, offset):
+        _check(lib.vsa_queries_set_offset(self._h, int(offset)))
+
     def close(self):
         if self._h:
             lib.vsa_queries_free(self._h)
@@ -255,6 +268,9 @@ class Result:
         s = Stats()
         _check(lib.vsa_result_getstats(self._h, C.byref(s)))
         return s
+
+    def copy_device(self, device_ptr, capacity):
+        _check(lib.vsa_result_copy_device(self._h, device_ptr, capacity))
 
     def fetch(self):
         n = self.count
@@ -300,6 +316,14 @@ def findmaximaluniquematches(index, searchlength):
     h = C.c_void_p()
     _check(lib.vsa_findmaximaluniquematches(index._h, int(searchlength),
                                             C.byref(h)))
+    return Result(h)
+
+
+def mumuniqueinquery(device_candidates, ncandidates, device=0):
+    """kurtz/cleanMUMcand.c:55 on candidates resident in device memory."""
+    h = C.c_void_p()
+    _check(lib.vsa_mumuniqueinquery(device_candidates, int(ncandidates),
+                                    device, C.byref(h)))
     return Result(h)
 
 
@@ -367,6 +391,10 @@ def synth_query_plan(n, nq, m, seed=QUERY_SEED):
 
 def device_count():
     return int(lib.vsa_device_count())
+
+
+def device_synchronize(device=0):
+    _check(lib.vsa_device_synchronize(device))
 
 
 def device_malloc(nbytes, device=0):

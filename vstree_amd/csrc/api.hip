@@ -31,6 +31,16 @@ extern "C" int vsa_device_count(void)
   return n;
 }
 
+extern "C" int vsa_device_synchronize(int device)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
 extern "C" int vsa_device_malloc(uint64_t bytes, int device, void **ptr)
 {
   if (vsa_set_device(device) != 0)
@@ -397,6 +407,7 @@ extern "C" int vsa_queries_from_host(const uint8_t *symbols,
   q->device = device;
   q->nq = nq;
   q->nsymbols = nsymbols;
+  q->seqoffset = 0;
   q->symbols = nullptr;
   q->start = q->length = nullptr;
   q->hlength.assign(length, length + nq);
@@ -447,6 +458,7 @@ extern "C" int vsa_queries_from_device(const void *device_symbols,
   q->device = device;
   q->nq = nq;
   q->nsymbols = nq * (uint64_t) m;
+  q->seqoffset = 0;
   q->symbols = nullptr;
   q->start = q->length = nullptr;
   q->hlength.assign(nq, (uint64_t) m);
@@ -469,6 +481,17 @@ extern "C" int vsa_queries_from_device(const void *device_symbols,
     VSA_HIP(hipGetLastError());
     VSA_HIP(hipDeviceSynchronize());
   }
+  return 0;
+}
+
+extern "C" int vsa_queries_set_offset(vsa_queries *q, uint64_t offset)
+{
+  if (q == nullptr)
+  {
+    VSA_ERROR("vsa_queries_set_offset: NULL argument");
+    return -1;
+  }
+  q->seqoffset = offset;
   return 0;
 }
 
@@ -511,6 +534,29 @@ extern "C" int vsa_result_fetch(const vsa_result *r, vsa_match *matches,
   }
   VSA_HIP(hipMemcpy(matches, r->matches, m * sizeof(vsa_match),
                     hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int vsa_result_copy_device(const vsa_result *r,
+                                      void *device_matches,
+                                      uint64_t capacity)
+{
+  if (r == nullptr || (device_matches == nullptr && capacity > 0))
+  {
+    VSA_ERROR("vsa_result_copy_device: NULL argument");
+    return -1;
+  }
+  const uint64_t m = std::min(capacity, r->count);
+  if (m == 0)
+  {
+    return 0;
+  }
+  if (vsa_set_device(r->device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipMemcpy(device_matches, r->matches, m * sizeof(vsa_match),
+                    hipMemcpyDeviceToDevice));
   return 0;
 }
 

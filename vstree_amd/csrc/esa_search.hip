@@ -126,7 +126,7 @@ k_complete_expand(const DevIndex<IDX> ix, const DevQueries qs, uint64_t nq,
   vsa_match m;
   m.length = qs.length[lo];
   m.dbstart = (uint64_t) ix.suf[left[lo] + (t - offsets[lo])];
-  m.queryseq = lo;
+  m.queryseq = lo + qs.seqoffset;
   m.querystart = 0;
   out[t] = m;
 }
@@ -322,14 +322,15 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
       vsa_match m;
       m.length = maxlcp;
       m.dbstart = (uint64_t) ix.suf[witness];
-      m.queryseq = q;
+      m.queryseq = q + qs.seqoffset;
       m.querystart = off;
       out[mybase] = m;
       outkey[mybase] = t;
     } else
     {
-      vsa_mem_walk<IDX, true>(ix, maxlcp, witness, leftchar, searchlength, q,
-                              off, out + mybase, outkey + mybase, t);
+      vsa_mem_walk<IDX, true>(ix, maxlcp, witness, leftchar, searchlength,
+                              q + qs.seqoffset, off, out + mybase,
+                              outkey + mybase, t);
     }
   }
 }
@@ -1097,6 +1098,50 @@ extern "C" int vsa_findquerymatches(const vsa_index *index,
   {
     vsa_result_free(res);
     return rc;
+  }
+  *result = res;
+  return 0;
+}
+
+extern "C" int vsa_mumuniqueinquery(void *device_candidates,
+                                    uint64_t ncandidates, int device,
+                                    vsa_result **result)
+{
+  if (result == nullptr || (device_candidates == nullptr && ncandidates > 0))
+  {
+    VSA_ERROR("vsa_mumuniqueinquery: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(device);
+  hipStream_t stream = nullptr; // default stream: no index handle here
+  Timer tall(stream);
+  DevBuf cand, mums;
+  cand.p = device_candidates; // borrowed, released below
+  uint64_t nm = 0;
+  tall.start();
+  const int rc = mumuniqueinquery(cand, ncandidates, stream, mums, &nm);
+  tall.stop();
+  cand.release();
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  (void) hipStreamSynchronize(stream);
+  res->count = nm;
+  res->matches = (vsa_match *) mums.release();
+  res->stats.count = nm;
+  res->stats.candidates = ncandidates;
+  res->stats.total_device_ms = tall.ms();
+  if (sumlengths(res->matches, nm, stream, &res->stats.sumlength) != 0)
+  {
+    vsa_result_free(res);
+    return -100;
   }
   *result = res;
   return 0;

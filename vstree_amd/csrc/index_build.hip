@@ -800,6 +800,72 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
 
 } // namespace
 
+// ---- sti1 (Mkvtree/mkvprocess.c:583-612) ------------------------------------
+
+// runstart[j] = j where lcp[j] < prefixlength (a new bucket run starts), else
+// 0; after a max-scan sti1[suf[j]] = min(255, j - runstart[j])
+__global__ void __launch_bounds__(VB_BLOCK)
+k_sti1_runstarts(const uint8_t *__restrict__ lcp, uint64_t count, uint32_t pl,
+                 uint32_t *__restrict__ runstart)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j < count)
+  {
+    runstart[j] = (j == 0 || lcp[j] < (uint8_t) pl) ? (uint32_t) j : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(VB_BLOCK)
+k_sti1_scatter(const uint32_t *__restrict__ sa,
+               const uint32_t *__restrict__ runstart, uint64_t count,
+               uint8_t *__restrict__ sti1)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  if (j < count)
+  {
+    const uint64_t d = j - runstart[j];
+    sti1[sa[j]] = (uint8_t) (d < 255 ? d : 255);
+  }
+}
+
+extern "C" int vsa_index_make_sti1(const vsa_index *ix, uint8_t *sti1)
+{
+  if (ix == nullptr || sti1 == nullptr)
+  {
+    VSA_ERROR("vsa_index_make_sti1: NULL argument");
+    return -1;
+  }
+  if (ix->isize != 4)
+  {
+    VSA_ERROR("vsa_index_make_sti1: 64-bit device tables are not supported");
+    return -2;
+  }
+  if (vsa_set_device(ix->device) != 0)
+  {
+    return -100;
+  }
+  const uint64_t count = ix->n + 1;
+  DevBuf runstart, out;
+  if (runstart.alloc(count * 4) || out.alloc(count))
+  {
+    return -100;
+  }
+  k_sti1_runstarts<<<gridfor(count), VB_BLOCK, 0, ix->stream>>>(
+      ix->lcp, count, ix->pl, runstart.as<uint32_t>());
+  VSA_HIP(hipGetLastError());
+  if (maxscan_inplace(runstart.as<uint32_t>(), count, ix->stream))
+  {
+    return -100;
+  }
+  k_sti1_scatter<<<gridfor(count), VB_BLOCK, 0, ix->stream>>>(
+      (const uint32_t *) ix->suf, runstart.as<uint32_t>(), count,
+      out.as<uint8_t>());
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipStreamSynchronize(ix->stream));
+  VSA_HIP(hipMemcpy(sti1, out.p, count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" int vsa_index_build(const uint8_t *tis, uint64_t totallength,
                                uint32_t numofchars, uint32_t prefixlength,
                                int device, vsa_index **index)

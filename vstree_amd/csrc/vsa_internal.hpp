@@ -100,7 +100,7 @@ struct vsa_queries
   uint64_t *length; // device [nq]
   // host copies of the lengths' summary, for validation without a sync
   uint64_t minlength, maxlength;
-  uint64_t firstshort_valid; // unused marker
+  uint64_t seqoffset; // added to queryseq of every match
   std::vector<uint64_t> hlength; // host copy (needed for ragged batches)
   bool uniform;                  // all lengths equal
 };
@@ -121,6 +121,7 @@ struct DevQueries
   const uint64_t *length;
   uint64_t nq;
   uint32_t uniformlen; // != 0: every query has this length
+  uint64_t seqoffset;
 };
 
 static inline DevQueries devqueries(const vsa_queries *q)
@@ -130,6 +131,7 @@ static inline DevQueries devqueries(const vsa_queries *q)
   d.start = q->start;
   d.length = q->length;
   d.nq = q->nq;
+  d.seqoffset = q->seqoffset;
   d.uniformlen = (q->uniform && q->maxlength < 0xFFFFFFFFull)
                      ? (uint32_t) q->maxlength
                      : 0;
