@@ -53,7 +53,7 @@ def parse():
                     help="queries per GPU (default 10 M)")
     ap.add_argument("--qlen", type=int, default=100)
     ap.add_argument("--minlen", type=int, default=20, help="vmatch -l")
-    ap.add_argument("--cpu-sample", type=int, default=200000,
+    ap.add_argument("--cpu-sample", type=int, default=1000000,
                     help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=1)
     return ap.parse_args()
@@ -90,10 +90,11 @@ def main():
 
     import vstree_amd as V
 
-    torch = dist = None
+    torch = dist = S = None
     if world > 1:
         import torch
         import torch.distributed as dist
+        from vstree_amd import sharding as S
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
@@ -147,32 +148,25 @@ def main():
         r = V.findquerymatches(index, queries, L, mum=True, cand=True)
         s = r.stats()
         kernel_ms.append(s.search_kernel_ms)
-        ncand = r.count
-        counts = torch.tensor([ncand], dtype=torch.int64, device="cuda")
-        allcounts = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(allcounts, counts)
-        allcounts = [int(c.item()) for c in allcounts]
-        cap = max(allcounts)
-        mine = torch.zeros(cap * 4, dtype=torch.int64, device="cuda")
-        r.copy_device(C.c_void_p(mine.data_ptr()), ncand)
+        mine = torch.zeros(max(r.count, 1) * 4, dtype=torch.int64,
+                           device="cuda")[:r.count * 4]
+        r.copy_device(C.c_void_p(mine.data_ptr()), r.count)
         r.close()
-        # phase 2: the one exchange step -- candidates to every rank over
-        # RCCL, uniqueness filter on rank 0
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        nmum = sumlen = 0
-        if rank == 0:
-            allc = torch.cat([g[:c * 4] for g, c in zip(gathered, allcounts)])
+
+        # phase 2: the one exchange step -- candidates of all ranks over
+        # RCCL, uniqueness filter (vsa_mumuniqueinquery) on rank 0
+        def filter_fn(allc):
             res = V.mumuniqueinquery(C.c_void_p(allc.data_ptr()),
-                                     sum(allcounts), dev)
+                                     allc.numel() // 4, dev)
             st = res.stats()
-            nmum, sumlen = st.count, st.sumlength
             res.close()
-        # final reduction of the match counters
-        red = torch.tensor([nmum, sumlen, s.searches, ncand],
-                           dtype=torch.int64, device="cuda")
-        dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        totals = tuple(int(x) for x in red.tolist())
+            return st.count, st.sumlength
+
+        nmum, sumlen, ncand = S.global_mum_filter(dist, torch, mine, "cuda",
+                                                  filter_fn)
+        # final reduction of the remaining match counters
+        searches, = S.all_reduce_counters(dist, torch, [s.searches], "cuda")
+        totals = (nmum, sumlen, searches, ncand)
 
     for _ in range(a.warmup):
         one_step()

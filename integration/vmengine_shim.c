@@ -1,0 +1,345 @@
+/*
+  Vmengine-side binding of the GPU engine: what a Vmatch maintainer adds.
+
+  It is compiled against the reference's OWN headers (src/include,
+  src/Vmengine) and linked into vmatch together with libvstree_amd.so using
+
+      -Wl,--wrap=findcompletematches -Wl,--wrap=findquerymatches
+      -Wl,--wrap=findmaximaluniquematches
+
+  so that every call site in src/Vmatch/runquery.c:97-115,149-169 and
+  src/Vmengine/fself.c:223 lands here unchanged.  Exact matching on the
+  index goes to the GPU; every other mode (-online, -e/-h/-xdrop, plugin
+  index, protein-vs-DNA, ...) is handed to the reference's own function
+  (__real_...), so this is a drop-in for the one path and nothing else.
+
+  Matches come back from the GPU in reference order and are reported through
+  the reference's own sinks -- processexactquerymatch
+  (src/Vmengine/procexqu.c:17) or a Match filled like
+  initcompletematchstruct (src/Vmengine/initcompl.c:7) -- on the calling
+  thread, so processfinal, SelectBundle plugins, E-values and output
+  formatting stay exactly what they were.
+
+  The uploaded index is kept between calls as long as the same Virtualtree
+  is passed (vmatch calls the engine once or twice per run: forward and
+  reverse-complement queries).
+*/
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "types.h"
+#include "errordef.h"
+#include "virtualdef.h"
+#include "multidef.h"
+#include "match.h"
+#include "select.h"
+#include "xdropdef.h"
+#include "matchstate.h"
+#include "mparms.h"
+#include "vplugin-interface.h"
+#include "cpridx-data.h"
+#include "vstree_amd.h"
+
+/* reference functions this binding keeps using */
+Sint initMatchstate(Matchstate *, Virtualtree *, void *, Matchparam *,
+                    Bestflag, Uint, Uint, SelectBundle *, Uint, void *,
+                    Currentdirection, BOOL, Processfinalfunction, Evalues *,
+                    BOOL);
+Sint processexactquerymatch(void *info, Uint l, Uint i, Uint queryseq,
+                            Uint querystart);
+void initcompletematchstruct(Match *match, Uint seqnum2, Uint plen,
+                             BOOL ispalindromic);
+Uint getqueryseppos(Multiseq *multiseq);
+
+Sint __real_findcompletematches(Virtualtree *, char *, Queryinfo *, BOOL,
+                                BOOL, Matchparam *, Bestflag, Uint, Uint,
+                                SelectBundle *, void *, Currentdirection,
+                                Processfinalfunction, Vpluginbundle *,
+                                Cpridxpatsearchdata *, Evalues *, BOOL);
+Sint __real_findquerymatches(Virtualtree *, Uint, Queryinfo *, BOOL, BOOL,
+                             BOOL, Matchparam *, Bestflag, Uint, Uint,
+                             SelectBundle *, void *, Currentdirection, BOOL,
+                             Processfinalfunction, Evalues *, BOOL);
+Sint __real_findmaximaluniquematches(Virtualtree *, Uint, Uint, void *,
+                                     void *, Outputfunction);
+
+static vsa_index *gpuindex = NULL;
+static Virtualtree *gpuindexowner = NULL;
+
+static int usegpu(void)
+{
+  const char *e = getenv("VMATCH_GPU");
+  return e == NULL || strcmp(e, "0") != 0;
+}
+
+static int gpufail(void)
+{
+  ERROR1("%s", vsa_messagespace());
+  return -1;
+}
+
+static int getgpuindex(Virtualtree *virtualtree, int needbwt,
+                       vsa_index **index)
+{
+  vsa_tables t;
+
+  if (gpuindex != NULL && gpuindexowner == virtualtree)
+  {
+    *index = gpuindex;
+    return 0;
+  }
+  if (gpuindex != NULL)
+  {
+    vsa_index_close(gpuindex);
+    gpuindex = NULL;
+  }
+  memset(&t, 0, sizeof t);
+  t.totallength = virtualtree->multiseq.totallength;
+  t.prefixlength = (uint32_t) virtualtree->prefixlength;
+  t.numofchars = (uint32_t) (virtualtree->alpha.mapsize - 1);
+  t.integersize = (uint32_t) (8 * sizeof(Uint));
+  t.largelcpvalues = virtualtree->largelcpvalues.nextfreePairUint;
+  t.tis = virtualtree->multiseq.sequence;
+  t.suf = virtualtree->suftab;
+  t.lcp = virtualtree->lcptab;
+  t.llv = virtualtree->largelcpvalues.spacePairUint;
+  t.bck = virtualtree->bcktab;
+  t.bwt = needbwt ? virtualtree->bwttab : NULL;
+  if (HASINDEXEDQUERIES(&virtualtree->multiseq))
+  {
+    t.hasindexedqueries = 1;
+    t.querysepposition = getqueryseppos(&virtualtree->multiseq);
+  }
+  if (vsa_index_from_tables(&t, 0, &gpuindex) != 0)
+  {
+    return gpufail();
+  }
+  gpuindexowner = virtualtree;
+  *index = gpuindex;
+  return 0;
+}
+
+/* the query Multiseq as (start, length) pairs, kurtz-basic/multiseq.c:129 */
+static int getgpuqueries(Multiseq *multiseq, BOOL rcmode,
+                         vsa_queries **queries)
+{
+  Uint i, nq = multiseq->numofsequences;
+  uint64_t *start, *length;
+  int rc;
+
+  start = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (nq + 1));
+  length = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (nq + 1));
+  if (start == NULL || length == NULL)
+  {
+    ERROR0("out of memory");
+    return -1;
+  }
+  for (i = 0; i < nq; i++)
+  {
+    Uint s = (i == 0) ? 0 : multiseq->markpos.spaceUint[i - 1] + 1;
+    Uint e = (i == nq - 1) ? multiseq->totallength
+                           : multiseq->markpos.spaceUint[i];
+    start[i] = s;
+    length[i] = e - s;
+  }
+  rc = vsa_queries_from_host(rcmode ? multiseq->rcsequence
+                                    : multiseq->sequence,
+                             multiseq->totallength, start, length, nq, 0,
+                             queries);
+  free(start);
+  free(length);
+  return rc != 0 ? gpufail() : 0;
+}
+
+/* ---- vmatch -complete -q ------------------------------------------------ */
+
+static int completesink(void *info, const vsa_match *m)
+{
+  Matchstate *matchstate = (Matchstate *) info;
+  Match match;
+
+  initcompletematchstruct(&match, (Uint) m->queryseq, (Uint) m->length,
+                          CHECKSHOWPALINDROMIC(matchstate) ? True : False);
+  match.length1 = (Uint) m->length;
+  match.distance = 0;
+  match.position1 = (Uint) m->dbstart;
+  return matchstate->processfinal(matchstate, &match) != 0 ? 1 : 0;
+}
+
+Sint __wrap_findcompletematches(Virtualtree *virtualtree,
+                                char *indexormatchfile, Queryinfo *queryinfo,
+                                BOOL rcmode, BOOL online,
+                                Matchparam *matchparam, Bestflag bestflag,
+                                Uint shownoevalue, Uint showselfpalindromic,
+                                SelectBundle *selectbundle,
+                                void *procmultiseq,
+                                Currentdirection currentdirection,
+                                Processfinalfunction processfinal,
+                                Vpluginbundle *cpridxpatsearchbundle,
+                                Cpridxpatsearchdata *cpridxpatsearchdata,
+                                Evalues *evalues, BOOL domatchbuffering)
+{
+  Matchstate matchstate;
+  vsa_index *index;
+  vsa_queries *queries;
+  int rc;
+
+  if (!usegpu() || online || !MPARMEXACTMATCH(&matchparam->maxdist) ||
+      cpridxpatsearchbundle->handle != NULL || virtualtree->suftab == NULL ||
+      virtualtree->bcktab == NULL || virtualtree->lcptab == NULL)
+  {
+    return __real_findcompletematches(
+        virtualtree, indexormatchfile, queryinfo, rcmode, online, matchparam,
+        bestflag, shownoevalue, showselfpalindromic, selectbundle,
+        procmultiseq, currentdirection, processfinal, cpridxpatsearchbundle,
+        cpridxpatsearchdata, evalues, domatchbuffering);
+  }
+  if (initMatchstate(&matchstate, virtualtree, (void *) queryinfo, matchparam,
+                     bestflag, shownoevalue, showselfpalindromic,
+                     selectbundle, 0, procmultiseq, currentdirection, False,
+                     processfinal, evalues, domatchbuffering) != 0)
+  {
+    return (Sint) -1;
+  }
+  cpridxpatsearchdata->voidMatchstate = NULL;
+  if (getgpuindex(virtualtree, 0, &index) != 0 ||
+      getgpuqueries(queryinfo->multiseq, rcmode, &queries) != 0)
+  {
+    return (Sint) -2;
+  }
+  rc = vsa_findcompletematches_cb(index, queries, completesink, &matchstate);
+  vsa_queries_free(queries);
+  if (rc != 0)
+  {
+    if (rc != -1) /* -1: the sink stopped the run, message is the sink's */
+    {
+      (void) gpufail();
+    }
+    return (Sint) -2;
+  }
+  return 0;
+}
+
+/* ---- vmatch [-mum [cand]] -l L -q --------------------------------------- */
+
+static int querysink(void *info, const vsa_match *m)
+{
+  return processexactquerymatch(info, (Uint) m->length, (Uint) m->dbstart,
+                                (Uint) m->queryseq, (Uint) m->querystart)
+                 != 0 ? 1 : 0;
+}
+
+Sint __wrap_findquerymatches(Virtualtree *virtualtree,
+                             Uint onlinequerynumoffset, Queryinfo *queryinfo,
+                             BOOL domaximaluniquematch,
+                             BOOL domaximaluniquematchcandidates, BOOL rcmode,
+                             Matchparam *matchparam, Bestflag bestflag,
+                             Uint shownoevalue, Uint showselfpalindromic,
+                             SelectBundle *selectbundle, void *procmultiseq,
+                             Currentdirection currentdirection,
+                             BOOL revmposorder,
+                             Processfinalfunction processfinal,
+                             Evalues *evalues, BOOL domatchbuffering)
+{
+  Matchstate matchstate;
+  vsa_index *index;
+  vsa_queries *queries;
+  int rc;
+
+  if (!usegpu() || !MPARMEXACTMATCH(&matchparam->maxdist) ||
+      matchparam->xdropbelowscore != UNDEFXDROPBELOWSCORE ||
+      virtualtree->suftab == NULL || virtualtree->bcktab == NULL ||
+      virtualtree->lcptab == NULL)
+  {
+    return __real_findquerymatches(
+        virtualtree, onlinequerynumoffset, queryinfo, domaximaluniquematch,
+        domaximaluniquematchcandidates, rcmode, matchparam, bestflag,
+        shownoevalue, showselfpalindromic, selectbundle, procmultiseq,
+        currentdirection, revmposorder, processfinal, evalues,
+        domatchbuffering);
+  }
+  if (initMatchstate(&matchstate, virtualtree, (void *) queryinfo, matchparam,
+                     bestflag, shownoevalue, showselfpalindromic,
+                     selectbundle, onlinequerynumoffset, procmultiseq,
+                     currentdirection, revmposorder, processfinal, evalues,
+                     domatchbuffering) != 0)
+  {
+    return (Sint) -1;
+  }
+  if (getgpuindex(virtualtree, 0, &index) != 0 ||
+      getgpuqueries(queryinfo->multiseq, rcmode, &queries) != 0)
+  {
+    return (Sint) -1;
+  }
+  rc = vsa_findquerymatches_cb(index, queries, domaximaluniquematch ? 1 : 0,
+                               domaximaluniquematchcandidates ? 1 : 0,
+                               matchparam->seedlength, querysink,
+                               &matchstate);
+  vsa_queries_free(queries);
+  if (rc != 0)
+  {
+    if (rc != -1)
+    {
+      (void) gpufail();
+    }
+    return (Sint) -1;
+  }
+  return 0;
+}
+
+/* ---- vmatch -mum -l L on an index that contains its queries ------------- */
+
+typedef struct
+{
+  void *outinfo;
+  Outputfunction output;
+} Selfsink;
+
+static int selfsink(void *info, const vsa_match *m)
+{
+  Selfsink *s = (Selfsink *) info;
+
+  return s->output(s->outinfo, (Uint) m->length, (Uint) m->dbstart,
+                   (Uint) m->queryseq) != 0 ? 1 : 0;
+}
+
+Sint __wrap_findmaximaluniquematches(Virtualtree *virtualtree,
+                                     Uint numberofprocessors,
+                                     Uint searchlength, void *repeatgapspec,
+                                     void *outinfo, Outputfunction output)
+{
+  vsa_index *index;
+  Selfsink s;
+  int rc;
+
+  if (!usegpu() || virtualtree->suftab == NULL ||
+      virtualtree->bcktab == NULL || virtualtree->lcptab == NULL ||
+      virtualtree->bwttab == NULL)
+  {
+    return __real_findmaximaluniquematches(virtualtree, numberofprocessors,
+                                           searchlength, repeatgapspec,
+                                           outinfo, output);
+  }
+  if (gpuindexowner == virtualtree && gpuindex != NULL)
+  {
+    /* make sure the cached copy carries bwt */
+    vsa_index_close(gpuindex);
+    gpuindex = NULL;
+  }
+  if (getgpuindex(virtualtree, 1, &index) != 0)
+  {
+    return (Sint) -3;
+  }
+  s.outinfo = outinfo;
+  s.output = output;
+  rc = vsa_findmaximaluniquematches_cb(index, searchlength, selfsink, &s);
+  if (rc != 0)
+  {
+    if (rc != -1)
+    {
+      (void) gpufail();
+    }
+    return (Sint) -3;
+  }
+  return 0;
+}

@@ -68,12 +68,15 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     manifest, arrays = {}, {}
 
-    def record(case, key, args, wd, selfmatch=False):
+    def record(case, key, args, wd, both=False):
         rc, lines, err = run_case(wd, args)
         entry = {"args": args, "rc": rc, "lines": len(lines),
                  "md5_lines": hashlib.md5(
                      ("\n".join(lines) + "\n").encode()).hexdigest()}
-        arrays["%s__%s" % (case, key)] = H.parse_vmatch_lines(lines)
+        if not both:   # lists with P lines are pinned by their md5 only
+            arrays["%s__%s" % (case, key)] = H.parse_vmatch_lines(lines)
+        else:
+            entry["strands"] = "both"
         if rc != 0:
             entry["stderr"] = err.strip()
         manifest[case]["runs"][key] = entry
@@ -208,6 +211,11 @@ def main():
                                "queries.fna", "genome.fna"], wd)
     record(case, "mum20", ["-mum", "-l", "20", "-q", "queries.fna",
                            "genome.fna"], wd)
+    # both strands (-d -p): reverse-complemented queries, flag P
+    record(case, "complete_dp", ["-complete", "-d", "-p", "-q", "queries.fna",
+                                 "genome.fna"], wd, both=True)
+    record(case, "mum20_dp", ["-mum", "-l", "20", "-d", "-p", "-q",
+                              "queries.fna", "genome.fna"], wd, both=True)
     shutil.rmtree(wd)
 
     np.savez_compressed(GOLD + "/expected.npz", **arrays)

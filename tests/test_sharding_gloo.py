@@ -1,0 +1,104 @@
+"""The N > 1 path on CPU: two ranks over gloo run the rank logic of
+vstree_amd/sharding.py.  The per-rank search is done by the CPU oracle here
+(the GPU kernels are covered by the -m gpu tests); what is under test is the
+sharding, the global query numbering, the candidate exchange and the counter
+reduction -- they must reproduce the reference's single-process output."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+WORLD = 2
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (H.ROOT, os.path.join(H.ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from vstree_amd import sharding as S
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx, q = H.load_case("c1")
+    first, count = S.shard_range(q.nq, rank, world)
+    mine = H.Queries(q.symbols, q.start[first:first + count],
+                     q.length[first:first + count])
+    # phase 1 (no communication): candidates of this rank's queries, numbered
+    # globally like vsa_queries_set_offset does
+    cand = H.oracle_querymatches(idx, mine, 20, mum=True, cand=True,
+                                 speedup=0)
+    cand["queryseq"] += np.uint64(first)
+    compl = H.oracle_complete(idx, mine)
+    compl["queryseq"] += np.uint64(first)
+    result = {}
+
+    def filter_fn(allc):
+        arr = S.tensor_to_matches(allc, H.MATCH_DTYPE)
+        import ctypes as C
+        out = H.OrcMatches()
+        lib = H.oracle_lib()
+        lib.orc_matches_init(C.byref(out))
+        arr = np.ascontiguousarray(arr)
+        lib.orc_mumuniqueinquery(arr.ctypes.data, len(arr), C.byref(out))
+        mums = H._take(out)
+        result["mums"] = mums
+        return len(mums), int(mums["length"].sum())
+
+    local = S.matches_to_tensor(torch, cand)
+    nmum, sumlen, ncand = S.global_mum_filter(dist, torch, local, "cpu",
+                                              filter_fn)
+    totals = S.all_reduce_counters(dist, torch,
+                                   [len(compl), int(compl["length"].sum())],
+                                   "cpu")
+    # -complete / candidates: concatenation in rank order = reference order
+    parts, counts = S.all_gather_matches(dist, torch,
+                                         S.matches_to_tensor(torch, compl),
+                                         "cpu")
+    if rank == 0:
+        allcompl = S.tensor_to_matches(torch.cat(parts), H.MATCH_DTYPE)
+        np.savez(os.path.join(outdir, "out.npz"), mums=result["mums"],
+                 compl=allcompl, nmum=nmum, sumlen=sumlen, ncand=ncand,
+                 totals=np.array(totals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_single_process_reference(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    H.load_case("c1")          # warm the oracle build before forking
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD,
+             join=True)
+    out = np.load(os.path.join(str(tmp_path), "out.npz"))
+    idx, q = H.load_case("c1")
+    want_mum = H.expected("c1", "mum20")
+    got_mum = H.matches_as_ref(idx, out["mums"])
+    assert np.array_equal(got_mum, want_mum)
+    assert int(out["nmum"]) == len(want_mum) == 10323
+    assert int(out["sumlen"]) == int(want_mum["length"].sum())
+    assert int(out["ncand"]) == len(H.expected("c1", "mumcand20"))
+    want_c = H.expected("c1", "complete")
+    assert np.array_equal(H.matches_as_ref(idx, out["compl"]), want_c)
+    assert out["totals"].tolist() == [len(want_c),
+                                      int(want_c["length"].sum())]
+
+
+def test_shard_range_covers_everything():
+    from vstree_amd import sharding as S
+    for total in (0, 1, 7, 10, 1000003):
+        for world in (1, 2, 3, 8):
+            blocks = [S.shard_range(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0
+            for (f, c), (f2, _) in zip(blocks, blocks[1:]):
+                assert f + c == f2
+            assert blocks[-1][0] + blocks[-1][1] == total
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1

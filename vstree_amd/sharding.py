@@ -1,0 +1,79 @@
+"""Rank logic of the multi-GPU query path (one process per GPU, index
+replicated, queries sharded), written against torch.distributed so that the
+same code runs over RCCL on MI355X (backend "nccl") and over gloo on CPU in
+the tests.
+
+Which step needs which collective:
+  -complete, -l, -mum cand   none on the data path; one all_reduce(sum) of
+                             the match counters
+  -mum (not cand)            the candidates of all ranks pass ONE global
+                             uniqueness filter (kurtz/cleanMUMcand.c:55-118 of
+                             the reference): all_gather of the candidate
+                             lists, filter on rank 0
+"""
+import numpy as np
+
+MATCH_WORDS = 4   # vsa_match = 4 x uint64
+
+
+def shard_range(total, rank, world):
+    """contiguous block of rank: (first, count); blocks differ by at most 1"""
+    base, extra = divmod(int(total), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def all_reduce_counters(dist, torch, values, device):
+    """sum of a handful of uint64 counters over all ranks"""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64,
+                     device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(x) for x in t.tolist()]
+
+
+def all_gather_matches(dist, torch, local, device):
+    """local: int64 tensor [count*4] of this rank's vsa_match records (on
+    `device`).  Returns (list of per-rank tensors trimmed to their counts,
+    counts).  Ragged lists are padded to the longest one for the collective."""
+    world = dist.get_world_size()
+    count = torch.tensor([local.numel() // MATCH_WORDS], dtype=torch.int64,
+                         device=device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    cap = max(counts) * MATCH_WORDS
+    padded = torch.zeros(max(cap, MATCH_WORDS), dtype=torch.int64,
+                         device=device)
+    padded[:local.numel()] = local
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
+    return [g[:c * MATCH_WORDS] for g, c in zip(gathered, counts)], counts
+
+
+def global_mum_filter(dist, torch, local_candidates, device, filter_fn):
+    """The one exchange step of `vmatch -mum` over sharded queries.
+    filter_fn(int64 tensor [n*4]) -> (number of MUMs, sum of their lengths);
+    it is called on rank 0 only.  Returns (mums, sumlength, candidates) as
+    job-wide totals on every rank."""
+    parts, counts = all_gather_matches(dist, torch, local_candidates, device)
+    nmum = sumlen = 0
+    if dist.get_rank() == 0:
+        allc = torch.cat(parts) if sum(counts) else torch.zeros(
+            0, dtype=torch.int64, device=device)
+        nmum, sumlen = filter_fn(allc)
+    nmum, sumlen = all_reduce_counters(dist, torch, [nmum, sumlen], device)
+    return nmum, sumlen, sum(counts)
+
+
+def matches_to_tensor(torch, matches, device="cpu"):
+    """structured numpy match array -> flat int64 tensor"""
+    flat = np.ascontiguousarray(matches).view(np.uint64).astype(np.int64)
+    return torch.from_numpy(flat.reshape(-1)).to(device)
+
+
+def tensor_to_matches(tensor, dtype):
+    a = tensor.cpu().numpy().astype(np.uint64).reshape(-1, MATCH_WORDS)
+    out = np.zeros(a.shape[0], dtype)
+    for i, name in enumerate(dtype.names):
+        out[name] = a[:, i]
+    return out
