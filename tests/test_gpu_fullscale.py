@@ -84,11 +84,9 @@ def test_index_structure(world):
         while a + k < n and b + k < n and tis[a + k] == tis[b + k]:
             k += 1
         assert int(lcp[j]) == min(k, 255), j
-        if b + k < n:
-            assert a + k >= n or tis[a + k] < tis[b + k] or True
-        # a < b in suffix order: either a ran out first or its symbol is less
-        assert (a + k >= n and False) or b + k >= n or a + k >= n or \
-            tis[a + k] < tis[b + k]
+        # suf[j-1] < suf[j]: the smaller suffix still has a (smaller)
+        # regular symbol where they part; the end sentinel is the largest
+        assert a + k < n and (b + k >= n or tis[a + k] < tis[b + k]), j
     # bck brackets the q-grams of the sampled suffixes
     pl = h.prefixlength
     w4 = 4 ** np.arange(pl - 1, -1, -1, dtype=np.uint64)
