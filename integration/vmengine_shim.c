@@ -313,8 +313,7 @@ Sint __wrap_findmaximaluniquematches(Virtualtree *virtualtree,
   int rc;
 
   if (!usegpu() || virtualtree->suftab == NULL ||
-      virtualtree->bcktab == NULL || virtualtree->lcptab == NULL ||
-      virtualtree->bwttab == NULL)
+      virtualtree->lcptab == NULL || virtualtree->bwttab == NULL)
   {
     return __real_findmaximaluniquematches(virtualtree, numberofprocessors,
                                            searchlength, repeatgapspec,

@@ -45,7 +45,7 @@ def stage(case, wd):
         if name.endswith(".gz"):
             with gzip.open(src, "rb") as f, open(wd + "/" + dst, "wb") as g:
                 g.write(f.read())
-        else:
+        elif not os.path.exists(wd + "/" + dst):
             shutil.copy(src, wd + "/" + dst)
     if case == "grumbach":
         shutil.copy(os.path.join(H.GOLDEN, "short.fna"), wd + "/short.fna")

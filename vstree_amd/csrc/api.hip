@@ -208,20 +208,25 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
     return -2;
   }
   if (t->tis == nullptr || t->suf == nullptr || t->lcp == nullptr ||
-      t->bck == nullptr || (t->largelcpvalues > 0 && t->llv == nullptr))
+      (t->largelcpvalues > 0 && t->llv == nullptr))
   {
-    VSA_ERROR("tables tis, suf, lcp, bck (and llv) are required");
+    VSA_ERROR("tables tis, suf, lcp (and llv) are required");
     return -3;
   }
-  if (t->prefixlength == 0 || t->numofchars == 0 || t->numofchars > 253)
+  // bck may be missing: vmatch does not map it for the self-index MUM scan
+  // (Vmatch/mapdemand.c:100-210); the query entry points then refuse to run
+  if (t->numofchars == 0 || t->numofchars > 253 ||
+      (t->bck != nullptr && t->prefixlength == 0))
   {
     VSA_ERROR("prefixlength=%u numofchars=%u: not a usable bucket table",
               t->prefixlength, t->numofchars);
     return -4;
   }
   vsa_index *ix = nullptr;
-  int rc = vsa_index_alloc(t->totallength, t->prefixlength, t->numofchars,
-                           t->largelcpvalues, t->bwt != nullptr, device, &ix);
+  int rc = vsa_index_alloc(t->totallength,
+                           t->bck != nullptr ? t->prefixlength : 0,
+                           t->numofchars, t->largelcpvalues,
+                           t->bwt != nullptr, device, &ix);
   if (rc != 0)
   {
     vsa_index_close(ix);
@@ -260,9 +265,15 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
     VSA_ERROR("upload failed");
     return fail(-100);
   }
+  if (t->bck == nullptr)
+  {
+    (void) hipFree(ix->bck);
+    ix->bck = nullptr;
+  }
   if (upload_integers(t->suf, t->integersize, n + 1, ix->isize, ix->suf, s) ||
-      upload_integers(t->bck, t->integersize, 2 * ix->numofcodes, ix->isize,
-                      ix->bck, s) ||
+      (t->bck != nullptr &&
+       upload_integers(t->bck, t->integersize, 2 * ix->numofcodes, ix->isize,
+                       ix->bck, s)) ||
       upload_integers(t->llv, t->integersize, 2 * ix->nllv, ix->isize,
                       ix->llv, s))
   {

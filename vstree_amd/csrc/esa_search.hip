@@ -1010,6 +1010,16 @@ extern "C" int vsa_findcompletematches(const vsa_index *index,
               queries->device, index->device);
     return -1;
   }
+  if (index->bck == nullptr)
+  {
+    VSA_ERROR("table bck is not loaded");
+    return -3;
+  }
+  if (queries->maxlength > 0xFFFFFFF0ull)
+  {
+    VSA_ERROR("query length beyond 32 bits is not supported");
+    return -3;
+  }
   if (vsa_set_device(index->device) != 0)
   {
     return -100;
@@ -1068,6 +1078,11 @@ extern "C" int vsa_findquerymatches(const vsa_index *index,
     VSA_ERROR("queries live on device %d, index on device %d",
               queries->device, index->device);
     return -1;
+  }
+  if (index->bck == nullptr)
+  {
+    VSA_ERROR("table bck is not loaded");
+    return -3;
   }
   // Vmengine/fquery.c:440-446
   if (searchlength < index->pl)
