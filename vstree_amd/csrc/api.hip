@@ -183,6 +183,7 @@ extern "C" void vsa_index_close(vsa_index *ix)
   (void) hipFree(ix->llv);
   (void) hipFree(ix->bck);
   (void) hipFree(ix->bwt);
+  (void) hipFree(ix->esa8);
   if (ix->stream != nullptr)
   {
     (void) hipStreamDestroy(ix->stream);
@@ -276,6 +277,10 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
                        ix->bck, s)) ||
       upload_integers(t->llv, t->integersize, 2 * ix->nllv, ix->isize,
                       ix->llv, s))
+  {
+    return fail(-100);
+  }
+  if (t->bck != nullptr && vsa_index_make_esa8(ix) != 0)
   {
     return fail(-100);
   }

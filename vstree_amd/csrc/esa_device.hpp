@@ -72,18 +72,125 @@ __device__ __forceinline__ int vsa_compare(const DevIndex<IDX> &ix,
   }
 }
 
+// ---- keyed probes ----------------------------------------------------------
+//
+// With the search array esa8 a probe of the in-bucket binary search is ONE
+// 8-byte load: suffix start, lcp byte and the VSA_KEYSYMS symbols that follow
+// the bucket prefix.  The comparison the reference makes on the text
+// (COMPARE) is answered from those symbols whenever it ends inside them --
+// in random-like sequence nearly always, except for the suffix that really
+// matches -- and continues on the text otherwise.  Result and probe order
+// are unchanged; only where the bytes come from differs.
+
+struct QueryKey
+{
+  uint32_t key;   // query symbols [pl, pl+VSA_KEYSYMS) packed like esa8's key
+  uint32_t valid; // how many of them are regular symbols inside the query
+};
+
+template <typename IDX>
+__device__ __forceinline__ QueryKey
+vsa_querykey(const DevIndex<IDX> &ix, const uint8_t *query, uint32_t querylen)
+{
+  QueryKey qk;
+  qk.key = 0;
+  qk.valid = 0;
+  bool open = true;
+#pragma unroll
+  for (uint32_t k = 0; k < VSA_KEYSYMS; k++)
+  {
+    const uint32_t p = ix.pl + k;
+    uint32_t c = 0;
+    if (open && p < querylen)
+    {
+      const uint8_t a = query[p];
+      if (VSA_ISSPECIAL(a))
+      {
+        open = false;
+      } else
+      {
+        c = a & 3;
+        qk.valid = k + 1;
+      }
+    } else
+    {
+      open = false;
+    }
+    qk.key = (qk.key << 2) | c;
+  }
+  return qk;
+}
+
+// probe of suffix-array entry i: keyed when esa8 is there, text otherwise
+template <typename IDX, bool KEYED>
+__device__ __forceinline__ int
+vsa_probe(const DevIndex<IDX> &ix, uint64_t i, const uint8_t *query,
+          uint32_t querylen, const QueryKey &qk, uint32_t &lcplen)
+{
+  if (!KEYED)
+  {
+    return vsa_compare(ix, (uint64_t) ix.suf[i], query, querylen, lcplen);
+  }
+  const uint64_t e = ix.esa8[i];
+  if ((e & VSA_KEYFLAG) == 0 && lcplen >= ix.pl)
+  {
+    const uint32_t d = lcplen - ix.pl;
+    const uint32_t limit = qk.valid; // <= VSA_KEYSYMS
+    if (d < limit)
+    {
+      const uint32_t tk = (uint32_t) (e >> VSA_KEYSHIFT) & VSA_KEYMASK;
+      // symbol p sits in bits [21-2p, 20-2p]; drop the positions < d
+      const uint32_t x = (tk ^ qk.key) & ((1u << (22 - 2 * d)) - 1u);
+      if (x != 0)
+      {
+        const uint32_t p = ((uint32_t) __builtin_clz(x) - 10u) >> 1;
+        if (p < limit)
+        {
+          lcplen = ix.pl + p;
+          const uint32_t sh = 20 - 2 * p;
+          return (int) ((qk.key >> sh) & 3) - (int) ((tk >> sh) & 3);
+        }
+      }
+      lcplen = ix.pl + limit; // equal as far as the key (or the query) goes
+    }
+  }
+  return vsa_compare(ix, e & 0xFFFFFFFFull, query, querylen, lcplen);
+}
+
+template <typename IDX, bool KEYED>
+__device__ __forceinline__ uint64_t vsa_sufstart(const DevIndex<IDX> &ix,
+                                                 uint64_t i)
+{
+  return KEYED ? (ix.esa8[i] & 0xFFFFFFFFull) : (uint64_t) ix.suf[i];
+}
+
+template <typename IDX, bool KEYED>
+__device__ __forceinline__ uint32_t vsa_lcpbyte(const DevIndex<IDX> &ix,
+                                                uint64_t i)
+{
+  return KEYED ? (uint32_t) (ix.esa8[i] >> 32) & 0xFFu : (uint32_t) ix.lcp[i];
+}
+
 // kurtz/findmaxpref.gen:1-96 (instantiated kurtz/maxpref.c:74-87): lcp-aware
 // binary search over suf[vleft..vright]; all suffixes there share `offset`
 // symbols with the query.  The probe sequence is the reference's, so the
 // witness is the reference's witness.
-template <typename IDX>
+template <typename IDX, bool KEYED>
 __device__ __forceinline__ void
 vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
                      uint32_t offset, const uint8_t *query, uint32_t querylen,
                      uint32_t &maxlcp, uint64_t &witness)
 {
+  QueryKey qk;
+  if (KEYED)
+  {
+    qk = vsa_querykey(ix, query, querylen);
+  } else
+  {
+    qk.key = qk.valid = 0;
+  }
   uint32_t lcplen = offset, lpref, rpref;
-  int ret = vsa_compare(ix, (uint64_t) ix.suf[vleft], query, querylen, lcplen);
+  int ret = vsa_probe<IDX, KEYED>(ix, vleft, query, querylen, qk, lcplen);
 
   maxlcp = lcplen;
   witness = vleft;
@@ -93,7 +200,7 @@ vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
   }
   lpref = lcplen;
   lcplen = offset;
-  ret = vsa_compare(ix, (uint64_t) ix.suf[vright], query, querylen, lcplen);
+  ret = vsa_probe<IDX, KEYED>(ix, vright, query, querylen, qk, lcplen);
   rpref = lcplen;
   if (lpref < rpref)
   {
@@ -113,7 +220,7 @@ vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
   while (right > left + 1)
   {
     const uint64_t mid = (left + right) >> 1;
-    ret = vsa_compare(ix, (uint64_t) ix.suf[mid], query, querylen, lcplen);
+    ret = vsa_probe<IDX, KEYED>(ix, mid, query, querylen, qk, lcplen);
     if (maxlcp < lcplen)
     {
       maxlcp = lcplen;

@@ -30,7 +30,7 @@
 
 // findsufboundaries, Vmengine/exactcompl.c:64-140: widen from the witness to
 // all suffixes sharing >= least symbols, inside the bucket [vleft, vright]
-template <typename IDX>
+template <typename IDX, bool KEYED>
 __device__ __forceinline__ void
 vsa_findsufboundaries(const DevIndex<IDX> &ix, uint32_t maxlcp,
                       uint64_t witness, uint32_t least, uint64_t vleft,
@@ -40,11 +40,13 @@ vsa_findsufboundaries(const DevIndex<IDX> &ix, uint32_t maxlcp,
 
   if (maxlcp < 255)
   {
-    for (i = witness; i != vleft && ix.lcp[i] >= (uint8_t) least; i--)
+    for (i = witness;
+         i != vleft && vsa_lcpbyte<IDX, KEYED>(ix, i) >= (least & 0xFFu); i--)
     {
     }
     l = i;
-    for (i = witness + 1; i <= vright && ix.lcp[i] >= (uint8_t) least; i++)
+    for (i = witness + 1;
+         i <= vright && vsa_lcpbyte<IDX, KEYED>(ix, i) >= (least & 0xFFu); i++)
     {
     }
     r = i - 1;
@@ -61,7 +63,7 @@ vsa_findsufboundaries(const DevIndex<IDX> &ix, uint32_t maxlcp,
   }
 }
 
-template <typename IDX>
+template <typename IDX, bool KEYED>
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_complete_search(const DevIndex<IDX> ix, const DevQueries qs,
                   uint64_t qlimit, uint64_t *__restrict__ outleft,
@@ -82,11 +84,12 @@ k_complete_search(const DevIndex<IDX> ix, const DevQueries qs,
     uint32_t maxlcp;
     uint64_t witness, r;
 
-    vsa_findmaxprefixlen(ix, vleft, vright, ix.pl, pattern, plen, maxlcp,
-                         witness);
+    vsa_findmaxprefixlen<IDX, KEYED>(ix, vleft, vright, ix.pl, pattern, plen,
+                                     maxlcp, witness);
     if (maxlcp >= plen)
     {
-      vsa_findsufboundaries(ix, maxlcp, witness, plen, vleft, vright, l, r);
+      vsa_findsufboundaries<IDX, KEYED>(ix, maxlcp, witness, plen, vleft,
+                                        vright, l, r);
       count = r - l + 1;
     }
   }
@@ -150,7 +153,7 @@ __device__ __forceinline__ bool vsa_leftmaximal(const DevIndex<IDX> &ix,
 // leftrightsubmatch, Vmengine/fquery.c:139-270 with the bounds algorithm 2
 // passes (left = 0, right = totallength-1, kurtz/matchsub.c:504-515).
 // WRITE = false counts the reports, WRITE = true stores them at out[0..).
-template <typename IDX, bool WRITE>
+template <typename IDX, bool KEYED, bool WRITE>
 __device__ __forceinline__ uint32_t
 vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
              uint8_t leftchar, uint32_t searchlength, uint64_t qseq,
@@ -162,7 +165,7 @@ vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
 
 #define VSA_REPORT(I, LEN)                                                    \
   {                                                                           \
-    const uint64_t ss_ = (uint64_t) ix.suf[I];                                \
+    const uint64_t ss_ = vsa_sufstart<IDX, KEYED>(ix, I);                     \
     if (vsa_leftmaximal(ix, ss_, leftchar))                                   \
     {                                                                         \
       if (WRITE)                                                              \
@@ -186,7 +189,8 @@ vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
     {
       break;
     }
-    lcpval = (maxlcp < 255) ? (uint64_t) ix.lcp[idx] : vsa_evallcp(ix, idx);
+    lcpval = (maxlcp < 255) ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, idx)
+                            : vsa_evallcp(ix, idx);
     if (lcpval < searchlength)
     {
       break;
@@ -199,7 +203,8 @@ vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
   minprefix = maxlcp;
   for (idx = witness + 1; idx <= right; idx++)
   {
-    lcpval = (maxlcp < 255) ? (uint64_t) ix.lcp[idx] : vsa_evallcp(ix, idx);
+    lcpval = (maxlcp < 255) ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, idx)
+                            : vsa_evallcp(ix, idx);
     if (lcpval < searchlength)
     {
       break;
@@ -217,7 +222,7 @@ vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
 // leftrightmaximaluniquematch, Vmengine/fquery.c:297-386, bounds as above.
 // The reference's branch for maxlcp >= 255 looks at the right neighbour only
 // if witness + 1 < right; kept as it stands.
-template <typename IDX>
+template <typename IDX, bool KEYED>
 __device__ __forceinline__ bool
 vsa_mum_candidate(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness)
 {
@@ -225,8 +230,10 @@ vsa_mum_candidate(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness)
 
   if (maxlcp < 255)
   {
-    return (witness == 0 || ix.lcp[witness] < (uint8_t) maxlcp) &&
-           (witness + 1 > right || ix.lcp[witness + 1] < (uint8_t) maxlcp);
+    return (witness == 0 ||
+            vsa_lcpbyte<IDX, KEYED>(ix, witness) < (maxlcp & 0xFFu)) &&
+           (witness + 1 > right ||
+            vsa_lcpbyte<IDX, KEYED>(ix, witness + 1) < (maxlcp & 0xFFu));
   }
   bool okay = (witness == 0) || vsa_evallcp(ix, witness) < maxlcp;
   if (okay && witness + 1 < right)
@@ -265,7 +272,7 @@ vsa_decode_workitem(const DevQueries &qs, const uint64_t *__restrict__ base,
   }
 }
 
-template <typename IDX, bool MUM>
+template <typename IDX, bool MUM, bool KEYED>
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
                const uint64_t *__restrict__ base, uint32_t perquery,
@@ -293,23 +300,24 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
     }
     if (vsa_bucket(ix, qptr, vleft, vright))
     {
-      vsa_findmaxprefixlen(ix, vleft, vright, ix.pl, qptr, remaining, maxlcp,
-                           witness);
+      vsa_findmaxprefixlen<IDX, KEYED>(ix, vleft, vright, ix.pl, qptr,
+                                       remaining, maxlcp, witness);
       found = maxlcp >= searchlength;
     }
     if (found)
     {
       if (MUM)
       {
-        c = (vsa_mum_candidate(ix, maxlcp, witness) &&
-             vsa_leftmaximal(ix, (uint64_t) ix.suf[witness], leftchar))
+        c = (vsa_mum_candidate<IDX, KEYED>(ix, maxlcp, witness) &&
+             vsa_leftmaximal(ix, vsa_sufstart<IDX, KEYED>(ix, witness),
+                             leftchar))
                 ? 1u
                 : 0u;
       } else
       {
-        c = vsa_mem_walk<IDX, false>(ix, maxlcp, witness, leftchar,
-                                     searchlength, q, off, nullptr, nullptr,
-                                     t);
+        c = vsa_mem_walk<IDX, KEYED, false>(ix, maxlcp, witness, leftchar,
+                                            searchlength, q, off, nullptr,
+                                            nullptr, t);
       }
     }
   }
@@ -321,16 +329,16 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
     {
       vsa_match m;
       m.length = maxlcp;
-      m.dbstart = (uint64_t) ix.suf[witness];
+      m.dbstart = vsa_sufstart<IDX, KEYED>(ix, witness);
       m.queryseq = q + qs.seqoffset;
       m.querystart = off;
       out[mybase] = m;
       outkey[mybase] = t;
     } else
     {
-      vsa_mem_walk<IDX, true>(ix, maxlcp, witness, leftchar, searchlength,
-                              q + qs.seqoffset, off, out + mybase,
-                              outkey + mybase, t);
+      vsa_mem_walk<IDX, KEYED, true>(ix, maxlcp, witness, leftchar,
+                                     searchlength, q + qs.seqoffset, off,
+                                     out + mybase, outkey + mybase, t);
     }
   }
 }
@@ -673,8 +681,15 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   tall.start();
   VSA_HIP(hipMemsetAsync(count.as<uint64_t>() + qlimit, 0, 8, stream));
   tsearch.start();
-  k_complete_search<IDX><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
-      ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+  if (ix.esa8 != nullptr)
+  {
+    k_complete_search<IDX, true><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+        ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+  } else
+  {
+    k_complete_search<IDX, false><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+        ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+  }
   tsearch.stop();
   VSA_HIP(hipGetLastError());
   size_t tb = 0;
@@ -854,17 +869,32 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     tsearch.start();
-    if (domum)
+#define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
+  k_query_search<IDX, MUMFLAG, KEYFLAG>                                       \
+      <<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(                            \
+          ix, qs, dbase, perquery, nitems, searchlength,                      \
+          out.as<vsa_match>(), keys.as<uint64_t>(), capacity,                 \
+          cursor.as<unsigned long long>())
+    if (ix.esa8 != nullptr)
     {
-      k_query_search<IDX, true><<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(
-          ix, qs, dbase, perquery, nitems, searchlength, out.as<vsa_match>(),
-          keys.as<uint64_t>(), capacity, cursor.as<unsigned long long>());
+      if (domum)
+      {
+        VSA_LAUNCH_QUERY(true, true);
+      } else
+      {
+        VSA_LAUNCH_QUERY(false, true);
+      }
     } else
     {
-      k_query_search<IDX, false><<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(
-          ix, qs, dbase, perquery, nitems, searchlength, out.as<vsa_match>(),
-          keys.as<uint64_t>(), capacity, cursor.as<unsigned long long>());
+      if (domum)
+      {
+        VSA_LAUNCH_QUERY(true, false);
+      } else
+      {
+        VSA_LAUNCH_QUERY(false, false);
+      }
     }
+#undef VSA_LAUNCH_QUERY
     tsearch.stop();
     VSA_HIP(hipGetLastError());
     VSA_HIP(hipMemcpyAsync(&needed, cursor.p, 8, hipMemcpyDeviceToHost,
@@ -989,6 +1019,63 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
 }
 
 } // namespace
+
+// ---------------------------------------------------------------------------
+// the keyed search array (see DevIndex::esa8)
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
+            const uint8_t *__restrict__ lcp, uint64_t count, uint32_t pl,
+            uint64_t *__restrict__ esa8)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (j >= count)
+  {
+    return;
+  }
+  const uint32_t s = suf[j];
+  const uint8_t *t = tis + (uint64_t) s + pl; // padded with 0xFF behind n
+  uint64_t key = 0, flag = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < VSA_KEYSYMS; k++)
+  {
+    const uint8_t a = t[k];
+    if (VSA_ISSPECIAL(a))
+    {
+      flag = VSA_KEYFLAG;
+    }
+    key = (key << 2) | (a & 3);
+  }
+  esa8[j] = (uint64_t) s | ((uint64_t) lcp[j] << 32) |
+            (key << VSA_KEYSHIFT) | flag;
+}
+
+int vsa_index_make_esa8(vsa_index *ix)
+{
+  const char *off = getenv("VSA_NO_ESA8");
+  if (ix->esa8 != nullptr)
+  {
+    (void) hipFree(ix->esa8);
+    ix->esa8 = nullptr;
+  }
+  if (ix->numofchars > 4 || ix->isize != 4 || ix->bck == nullptr ||
+      (off != nullptr && strcmp(off, "1") == 0))
+  {
+    return 0;
+  }
+  // the key window may reach VSA_KEYSYMS symbols past the text end
+  static_assert(VSA_TIS_BACKPAD >= VSA_KEYSYMS + 8, "text pad too small");
+  const uint64_t count = ix->n + 1;
+  VSA_HIP(hipMalloc((void **) &ix->esa8, count * 8 + 64));
+  ix->device_bytes += count * 8;
+  k_make_esa8<<<gridfor(count), VSA_BLOCK, 0, ix->stream>>>(
+      ix->tis_alloc + VSA_TIS_FRONTPAD, (const uint32_t *) ix->suf, ix->lcp,
+      count, ix->pl, ix->esa8);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipStreamSynchronize(ix->stream));
+  return 0;
+}
 
 // ---------------------------------------------------------------------------
 // C ABI

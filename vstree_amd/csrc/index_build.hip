@@ -789,6 +789,10 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
     }
   }
   rc = build_tables(ix);
+  if (rc == 0)
+  {
+    rc = vsa_index_make_esa8(ix);
+  }
   if (rc != 0)
   {
     vsa_index_close(ix);

@@ -39,7 +39,7 @@ extern "C" char *vsa_errbuf();
 // reproduces "sptr >= sentinel => retcode = -1" (kurtz/maxpref.c:57-61)
 // without a bounds test; 8-byte loads may run 7 bytes past it.
 #define VSA_TIS_FRONTPAD 16
-#define VSA_TIS_BACKPAD 32
+#define VSA_TIS_BACKPAD 64
 // queries are compared 8 bytes at a time, too
 #define VSA_QUERY_BACKPAD 16
 
@@ -54,9 +54,20 @@ struct DevIndex
   const IDX *llv;     // [2*nllv]
   const IDX *bck;     // [2*numofcodes]
   const uint8_t *bwt; // [n+1] or nullptr
+  // [n+1] or nullptr: per suffix {suf:32 | lcp byte:8 | key:22 | flag:1},
+  // key = the VSA_KEYSYMS symbols behind the first pl ones, 2 bits each,
+  // first symbol most significant; flag = a special symbol in that window.
+  // One 8-byte load answers most probes of the in-bucket search without
+  // touching the text (DNA alphabets with 32-bit suf only).
+  const uint64_t *esa8;
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars;
 };
+
+#define VSA_KEYSYMS 11u
+#define VSA_KEYSHIFT 40u
+#define VSA_KEYMASK 0x3FFFFFu
+#define VSA_KEYFLAG (1ull << 62)
 
 struct vsa_index
 {
@@ -68,6 +79,7 @@ struct vsa_index
   uint8_t *tis_alloc; // allocation; text starts at tis_alloc + FRONTPAD
   void *suf, *llv, *bck;
   uint8_t *lcp, *bwt;
+  uint64_t *esa8; // search array, see DevIndex (may be nullptr)
   uint64_t querysepposition;
   int hasindexedqueries;
   uint64_t device_bytes;
@@ -82,6 +94,7 @@ struct vsa_index
     v.llv = (const IDX *) llv;
     v.bck = (const IDX *) bck;
     v.bwt = bwt;
+    v.esa8 = esa8;
     v.n = n;
     v.nllv = nllv;
     v.numofcodes = numofcodes;
@@ -139,6 +152,10 @@ static inline DevQueries devqueries(const vsa_queries *q)
 }
 
 int vsa_set_device(int device);
+
+// builds the keyed search array from tis/suf/lcp (esa_search.hip); a no-op
+// for alphabets beyond 4 symbols, 64-bit tables or VSA_NO_ESA8=1
+int vsa_index_make_esa8(vsa_index *ix);
 
 // device tables of the given shape, contents undefined (api.hip)
 int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
