@@ -232,3 +232,65 @@ def test_repeats_beyond_255_and_many_occurrences(V):
             a = V.findquerymatches(gi, gq, L, **kw).fetch()
             b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
             assert np.array_equal(a, b), (L, kw)
+
+
+@pytest.mark.parametrize("mode", ["reference_walk", "deep7", "deep9",
+                                  "deep12"])
+def test_both_locate_strategies_give_the_same_lists(V, mode, monkeypatch):
+    """the deep locate (bck2 + esa8) and the reference walk (bck + binary
+    search on suf/tis) must be indistinguishable from outside"""
+    if mode == "reference_walk":
+        monkeypatch.setenv("VSA_NO_ESA8", "1")
+    else:
+        monkeypatch.setenv("VSA_DEEP_PREFIX", mode[4:])
+    idx, q = H.load_case("c1")
+    gi = V.Index.from_tables(idx.n, idx.prefixlength, 4, idx.tis,
+                             idx.suf.astype(np.uint32), idx.lcp,
+                             idx.llv.astype(np.uint32),
+                             idx.bck.astype(np.uint32), idx.bwt)
+    gq = gpu_queries(V, q)
+    got = H.matches_as_ref(idx, V.findcompletematches(gi, gq).fetch())
+    assert np.array_equal(got, H.expected("c1", "complete"))
+    for key, kw in (("mem20_sp0", {}), ("mumcand20", dict(mum=True,
+                                                          cand=True)),
+                    ("mum20", dict(mum=True))):
+        got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
+                                                       **kw).fetch())
+        assert np.array_equal(got, H.expected("c1", key)), (mode, key)
+    # a search length below the deep prefix falls back by itself
+    a = V.findquerymatches(gi, gq, 8).fetch()
+    assert np.array_equal(a, H.oracle_querymatches(idx, q, 8, speedup=0))
+
+
+def test_deep_locate_on_repeats_and_ties(V):
+    """ties on the key (several suffixes share D+11 symbols), wildcards next
+    to matches, queries that end inside the key window"""
+    rng = np.random.default_rng(21)
+    unit = rng.integers(0, 4, size=60).astype(np.uint8)
+    parts = [np.tile(unit, 30), rng.integers(0, 4, 4000).astype(np.uint8),
+             np.array([H.WILDCARD], np.uint8), np.tile(unit, 3),
+             np.array([H.SEPARATOR], np.uint8),
+             rng.integers(0, 4, 4000).astype(np.uint8), unit[:40],
+             np.array([H.WILDCARD], np.uint8), unit[:33]]
+    tis = np.concatenate(parts)
+    idx = H.oracle_build_index(tis, 4, 3)
+    gi = V.Index.from_tables(idx.n, idx.prefixlength, 4, idx.tis,
+                             idx.suf.astype(np.uint32), idx.lcp,
+                             idx.llv.astype(np.uint32),
+                             idx.bck.astype(np.uint32), idx.bwt)
+    assert gi.info().prefixlength == 3
+    seqs = [unit, unit[:20], unit[5:17], unit[:9], np.tile(unit, 2),
+            np.concatenate([unit[:30], [254], unit[31:]]).astype(np.uint8),
+            tis[2000:2100], tis[1790:1830], tis[5990:6110]]
+    for L in range(6, 40, 3):
+        for p in (0, 7, 1234, 3000, 5000, 9000):
+            seqs.append(tis[p:p + L])
+    q = H.Queries.from_list(seqs)
+    gq = gpu_queries(V, q)
+    assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
+                          H.oracle_complete(idx, q))
+    for L in (6, 7, 9, 12, 18, 25):
+        for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
+            a = V.findquerymatches(gi, gq, L, **kw).fetch()
+            b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
+            assert np.array_equal(a, b), (L, kw)

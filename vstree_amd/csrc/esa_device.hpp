@@ -1,14 +1,33 @@
 // Device-side primitives of the enhanced-suffix-array search, CDNA4 (gfx950).
 //
 // One work-item owns one search (one query for -complete, one query suffix
-// for -l / -mum): the path is a chain of dependent random reads
-// (bck -> suf -> tis -> ... -> lcp), so throughput comes from the number of
-// independent chains in flight, 64 per wavefront and thousands of wavefronts
-// per launch, not from lanes cooperating on one chain.  Text and query are
-// compared eight symbols per 64-bit load.
+// for -l / -mum): the path is a chain of dependent random reads, so
+// throughput comes from the number of independent chains in flight (64 per
+// wavefront, 32 wavefronts per CU) and from how FEW dependent steps each
+// wavefront needs -- a wavefront advances at the pace of its slowest lane,
+// and every step costs one loaded memory latency (~1000 cycles measured).
 //
-// Semantics follow the reference exactly (paths relative to
-// /root/reference/src); each function names its counterpart.
+// Two ways to locate a query suffix Q in the index:
+//
+//   reference walk   bucket of the first prefixlength symbols (bck) + the
+//                    lcp-aware binary search of kurtz/findmaxpref.gen on
+//                    suf/tis.  Probe for probe the reference's algorithm.
+//   deep locate      an internal, deeper bucket table (bck2, D symbols, about
+//                    one to three suffixes per bucket) + the keyed array esa8
+//                    {suf:32, lcp byte:8, key:22 = the 11 symbols behind the
+//                    first D, flag:1}: a short, wavefront-uniform search on
+//                    keys, then ONE text comparison for the lanes whose key
+//                    ties.  ~10 dependent steps instead of ~140, ~3 random
+//                    64-byte sectors instead of ~15.
+//
+// Both deliver the same two numbers the reference computes -- the maximal
+// matched length and a suffix attaining it -- and everything reported is a
+// function of those.  The one place where the
+// reference's probe ORDER shows (which of several equally good suffixes is
+// the "witness" the MEM enumeration starts from) is reproduced by replaying
+// the probe sequence arithmetically (vsa_reference_witness).
+//
+// Semantics follow the reference (paths relative to /root/reference/src).
 #pragma once
 
 #include "vsa_internal.hpp"
@@ -72,91 +91,7 @@ __device__ __forceinline__ int vsa_compare(const DevIndex<IDX> &ix,
   }
 }
 
-// ---- keyed probes ----------------------------------------------------------
-//
-// With the search array esa8 a probe of the in-bucket binary search is ONE
-// 8-byte load: suffix start, lcp byte and the VSA_KEYSYMS symbols that follow
-// the bucket prefix.  The comparison the reference makes on the text
-// (COMPARE) is answered from those symbols whenever it ends inside them --
-// in random-like sequence nearly always, except for the suffix that really
-// matches -- and continues on the text otherwise.  Result and probe order
-// are unchanged; only where the bytes come from differs.
-
-struct QueryKey
-{
-  uint32_t key;   // query symbols [pl, pl+VSA_KEYSYMS) packed like esa8's key
-  uint32_t valid; // how many of them are regular symbols inside the query
-};
-
-template <typename IDX>
-__device__ __forceinline__ QueryKey
-vsa_querykey(const DevIndex<IDX> &ix, const uint8_t *query, uint32_t querylen)
-{
-  QueryKey qk;
-  qk.key = 0;
-  qk.valid = 0;
-  bool open = true;
-#pragma unroll
-  for (uint32_t k = 0; k < VSA_KEYSYMS; k++)
-  {
-    const uint32_t p = ix.pl + k;
-    uint32_t c = 0;
-    if (open && p < querylen)
-    {
-      const uint8_t a = query[p];
-      if (VSA_ISSPECIAL(a))
-      {
-        open = false;
-      } else
-      {
-        c = a & 3;
-        qk.valid = k + 1;
-      }
-    } else
-    {
-      open = false;
-    }
-    qk.key = (qk.key << 2) | c;
-  }
-  return qk;
-}
-
-// probe of suffix-array entry i: keyed when esa8 is there, text otherwise
-template <typename IDX, bool KEYED>
-__device__ __forceinline__ int
-vsa_probe(const DevIndex<IDX> &ix, uint64_t i, const uint8_t *query,
-          uint32_t querylen, const QueryKey &qk, uint32_t &lcplen)
-{
-  if (!KEYED)
-  {
-    return vsa_compare(ix, (uint64_t) ix.suf[i], query, querylen, lcplen);
-  }
-  const uint64_t e = ix.esa8[i];
-  if ((e & VSA_KEYFLAG) == 0 && lcplen >= ix.pl)
-  {
-    const uint32_t d = lcplen - ix.pl;
-    const uint32_t limit = qk.valid; // <= VSA_KEYSYMS
-    if (d < limit)
-    {
-      const uint32_t tk = (uint32_t) (e >> VSA_KEYSHIFT) & VSA_KEYMASK;
-      // symbol p sits in bits [21-2p, 20-2p]; drop the positions < d
-      const uint32_t x = (tk ^ qk.key) & ((1u << (22 - 2 * d)) - 1u);
-      if (x != 0)
-      {
-        const uint32_t p = ((uint32_t) __builtin_clz(x) - 10u) >> 1;
-        if (p < limit)
-        {
-          lcplen = ix.pl + p;
-          const uint32_t sh = 20 - 2 * p;
-          return (int) ((qk.key >> sh) & 3) - (int) ((tk >> sh) & 3);
-        }
-      }
-      lcplen = ix.pl + limit; // equal as far as the key (or the query) goes
-    }
-  }
-  return vsa_compare(ix, e & 0xFFFFFFFFull, query, querylen, lcplen);
-}
-
+// table accessors: esa8 carries suf and the lcp byte next to each other
 template <typename IDX, bool KEYED>
 __device__ __forceinline__ uint64_t vsa_sufstart(const DevIndex<IDX> &ix,
                                                  uint64_t i)
@@ -175,22 +110,14 @@ __device__ __forceinline__ uint32_t vsa_lcpbyte(const DevIndex<IDX> &ix,
 // binary search over suf[vleft..vright]; all suffixes there share `offset`
 // symbols with the query.  The probe sequence is the reference's, so the
 // witness is the reference's witness.
-template <typename IDX, bool KEYED>
+template <typename IDX>
 __device__ __forceinline__ void
 vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
                      uint32_t offset, const uint8_t *query, uint32_t querylen,
                      uint32_t &maxlcp, uint64_t &witness)
 {
-  QueryKey qk;
-  if (KEYED)
-  {
-    qk = vsa_querykey(ix, query, querylen);
-  } else
-  {
-    qk.key = qk.valid = 0;
-  }
   uint32_t lcplen = offset, lpref, rpref;
-  int ret = vsa_probe<IDX, KEYED>(ix, vleft, query, querylen, qk, lcplen);
+  int ret = vsa_compare(ix, (uint64_t) ix.suf[vleft], query, querylen, lcplen);
 
   maxlcp = lcplen;
   witness = vleft;
@@ -200,7 +127,7 @@ vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
   }
   lpref = lcplen;
   lcplen = offset;
-  ret = vsa_probe<IDX, KEYED>(ix, vright, query, querylen, qk, lcplen);
+  ret = vsa_compare(ix, (uint64_t) ix.suf[vright], query, querylen, lcplen);
   rpref = lcplen;
   if (lpref < rpref)
   {
@@ -220,7 +147,7 @@ vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
   while (right > left + 1)
   {
     const uint64_t mid = (left + right) >> 1;
-    ret = vsa_probe<IDX, KEYED>(ix, mid, query, querylen, qk, lcplen);
+    ret = vsa_compare(ix, (uint64_t) ix.suf[mid], query, querylen, lcplen);
     if (maxlcp < lcplen)
     {
       maxlcp = lcplen;
@@ -247,6 +174,42 @@ vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
       break;
     }
   }
+}
+
+// The witness findmaxpref.gen ends with, given the bucket [vleft, vright] it
+// searches and the interval [l, r] of the suffixes that attain the maximal
+// matched length: the first probe of its fixed sequence (vleft, vright, then
+// bisection towards the query's position) that falls into [l, r].  Every
+// suffix left of l is smaller than the query and every suffix right of r is
+// larger, which is all the bisection looks at; only a probe inside [l, r]
+// raises the running maximum to its final value (findmaxpref.gen:57-63).
+__device__ __forceinline__ uint64_t
+vsa_reference_witness(uint64_t vleft, uint64_t vright, uint64_t l, uint64_t r)
+{
+  if (vleft >= l) // vleft <= r always: the bucket contains [l, r]
+  {
+    return vleft;
+  }
+  if (vright <= r)
+  {
+    return vright;
+  }
+  uint64_t left = vleft, right = vright;
+  while (right > left + 1)
+  {
+    const uint64_t mid = (left + right) >> 1;
+    if (mid < l)
+    {
+      left = mid;
+    } else if (mid > r)
+    {
+      right = mid;
+    } else
+    {
+      return mid;
+    }
+  }
+  return l; // not reached: [l, r] lies strictly between left and right
 }
 
 // getexception, kurtz-basic/accvirt.c:69-150: value of the lcp entry i whose
@@ -338,6 +301,230 @@ __device__ __forceinline__ bool vsa_bucket(const DevIndex<IDX> &ix,
   }
   vright--;
   return true;
+}
+
+// the reference's way to a (maxlcp, witness) pair
+template <typename IDX>
+__device__ __forceinline__ bool
+vsa_locate_reference(const DevIndex<IDX> &ix, const uint8_t *query,
+                     uint32_t querylen, uint32_t &maxlcp, uint64_t &witness)
+{
+  uint64_t vleft, vright;
+
+  if (!vsa_bucket(ix, query, vleft, vright))
+  {
+    return false;
+  }
+  vsa_findmaxprefixlen(ix, vleft, vright, ix.pl, query, querylen, maxlcp,
+                       witness);
+  return true;
+}
+
+// ---- deep locate (DNA, 32-bit tables) -------------------------------------
+
+// eight symbols (one byte each, 0..3) -> 16 bits, first symbol most
+// significant, so that integers compare like the strings they pack
+__device__ __forceinline__ uint64_t vsa_pack8(uint64_t w)
+{
+  uint64_t x = __builtin_bswap64(w) & 0x0303030303030303ull;
+  x = (x | (x >> 6)) & 0x000F000F000F000Full;
+  x = (x | (x >> 12)) & 0x000000FF000000FFull;
+  x = (x | (x >> 24)) & 0xFFFFull;
+  return x;
+}
+
+// number of leading key symbols (2 bits each, `nsyms` of them in the low
+// bits of a and b) that agree
+__device__ __forceinline__ uint32_t vsa_keylcp(uint32_t a, uint32_t b,
+                                               uint32_t nsyms)
+{
+  const uint32_t x = (a ^ b) & ((1u << (2 * nsyms)) - 1u);
+  if (x == 0)
+  {
+    return nsyms;
+  }
+  // highest differing bit h -> symbol (2*nsyms-1-h)/2 counted from the front
+  const uint32_t h = 31u - (uint32_t) __builtin_clz(x);
+  return (2 * nsyms - 1 - h) >> 1;
+}
+
+enum
+{
+  VSA_LOC_NONE = 0, // nothing in the index shares D symbols with the query
+  VSA_LOC_FOUND = 1,
+  VSA_LOC_SLOW = 2  // take the reference walk (special symbols, ties, ...)
+};
+
+// Deep locate.  Must be called by all lanes of the wavefront (inactive lanes
+// pass active = false): the key search runs a wavefront-uniform number of
+// rounds.  On VSA_LOC_FOUND: maxlcp = the maximal matched length over the
+// whole index, w = a suffix-array index attaining it.
+__device__ __forceinline__ int
+vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
+                const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
+                uint64_t &w)
+{
+  const uint32_t D = ix.D;
+  int state = VSA_LOC_NONE;
+  uint32_t dl = 0, cnt = 0, qkey = 0, limit = 0;
+
+  if (active)
+  {
+    // 32 query symbols as four 8-byte words (the buffer is padded)
+    const uint64_t w0 = vsa_load8(query), w1 = vsa_load8(query + 8),
+                   w2 = vsa_load8(query + 16), w3 = vsa_load8(query + 24);
+    const uint64_t s0 = vsa_specialmask(w0), s1 = vsa_specialmask(w1),
+                   s2 = vsa_specialmask(w2), s3 = vsa_specialmask(w3);
+    uint32_t valid = 32; // leading regular symbols inside the query
+    if (s0 != 0)
+    {
+      valid = (uint32_t) __builtin_ctzll(s0) >> 3;
+    } else if (s1 != 0)
+    {
+      valid = 8 + ((uint32_t) __builtin_ctzll(s1) >> 3);
+    } else if (s2 != 0)
+    {
+      valid = 16 + ((uint32_t) __builtin_ctzll(s2) >> 3);
+    } else if (s3 != 0)
+    {
+      valid = 24 + ((uint32_t) __builtin_ctzll(s3) >> 3);
+    }
+    if (valid > querylen)
+    {
+      valid = querylen;
+    }
+    if (valid < ix.pl)
+    {
+      state = VSA_LOC_NONE; // qgram2code fails or query shorter than pl
+    } else if (valid < D)
+    {
+      state = VSA_LOC_SLOW;
+    } else
+    {
+      const uint64_t S = (vsa_pack8(w0) << 48) | (vsa_pack8(w1) << 32) |
+                         (vsa_pack8(w2) << 16) | vsa_pack8(w3);
+      const uint64_t code = S >> (64 - 2 * D);
+      qkey = (uint32_t) (S >> (64 - 2 * D - 2 * VSA_KEYSYMS)) & VSA_KEYMASK;
+      limit = valid - D;
+      if (limit > VSA_KEYSYMS)
+      {
+        limit = VSA_KEYSYMS;
+      }
+      // (left, mid) of the deep bucket: one 8-byte load
+      const uint2 b = *reinterpret_cast<const uint2 *>(ix.bck2 + 2 * code);
+      dl = b.x;
+      cnt = (b.y > b.x) ? b.y - b.x : 0;
+      state = (cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
+    }
+  }
+  const bool searching = state == VSA_LOC_FOUND;
+  // only the first `limit` key symbols of the query exist
+  const uint32_t qk = qkey >> (2 * (VSA_KEYSYMS - limit));
+
+  // lower bound on keys: ins = number of bucket entries whose key is smaller
+  // than the query's.  Trip count = that of the largest bucket in the
+  // wavefront, so the lanes stay converged.
+  uint32_t lo = 0, hi = searching ? cnt : 0;
+  bool flagged = false;
+  uint32_t maxcnt = hi;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1)
+  {
+    const uint32_t o = __shfl_xor(maxcnt, d, 64);
+    maxcnt = o > maxcnt ? o : maxcnt;
+  }
+  for (uint32_t span = maxcnt; span > 0; span >>= 1)
+  {
+    if (lo < hi)
+    {
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint64_t e = ix.esa8[(uint64_t) dl + mid];
+      flagged = flagged || (e & VSA_KEYFLAG) != 0;
+      const uint32_t tk = ((uint32_t) (e >> VSA_KEYSHIFT) & VSA_KEYMASK) >>
+                          (2 * (VSA_KEYSYMS - limit));
+      if (tk < qk)
+      {
+        lo = mid + 1;
+      } else
+      {
+        hi = mid;
+      }
+    }
+  }
+  // neighbours of the insertion point: pred = lo-1, succ = lo, and succ+1
+  // for the size of a tie; three independent loads
+  uint64_t epred = 0, esucc = 0, enext = 0;
+  bool haspred = false, hassucc = false, hasnext = false;
+  if (searching)
+  {
+    const uint64_t base = (uint64_t) dl + lo;
+    haspred = lo > 0;
+    hassucc = lo < cnt;
+    hasnext = lo + 1 < cnt;
+    if (haspred)
+    {
+      epred = ix.esa8[base - 1];
+    }
+    if (hassucc)
+    {
+      esucc = ix.esa8[base];
+    }
+    if (hasnext)
+    {
+      enext = ix.esa8[base + 1];
+    }
+    flagged = flagged || (haspred && (epred & VSA_KEYFLAG) != 0) ||
+              (hassucc && (esucc & VSA_KEYFLAG) != 0);
+  }
+  bool extend = false; // key tie: the text decides
+  if (searching)
+  {
+    if (flagged)
+    {
+      state = VSA_LOC_SLOW;
+    } else
+    {
+      const uint32_t sh = 2 * (VSA_KEYSYMS - limit);
+      const uint32_t kp = ((uint32_t) (epred >> VSA_KEYSHIFT) & VSA_KEYMASK)
+                          >> sh,
+                     ks = ((uint32_t) (esucc >> VSA_KEYSHIFT) & VSA_KEYMASK)
+                          >> sh;
+      const uint32_t lp = haspred ? vsa_keylcp(kp, qk, limit) : 0,
+                     ls = hassucc ? vsa_keylcp(ks, qk, limit) : 0;
+      if (hassucc && ls == limit)
+      {
+        // succ ties with the query on all key symbols.  More than one tying
+        // suffix (lcp byte of the next entry >= D + limit) is left to the
+        // reference walk.
+        const uint32_t nextlcp = (uint32_t) (enext >> 32) & 0xFFu;
+        if (hasnext && nextlcp >= D + limit)
+        {
+          state = VSA_LOC_SLOW;
+        } else
+        {
+          extend = true;
+          w = (uint64_t) dl + lo;
+          maxlcp = D + limit;
+        }
+      } else if (ls > lp || !haspred)
+      {
+        w = (uint64_t) dl + lo;
+        maxlcp = D + ls;
+      } else
+      {
+        w = (uint64_t) dl + lo - 1;
+        maxlcp = D + lp;
+      }
+    }
+  }
+  // one text comparison for the lanes with a tie, all at the same time
+  if (extend)
+  {
+    uint32_t lcplen = maxlcp;
+    (void) vsa_compare(ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
+    maxlcp = lcplen;
+  }
+  return state;
 }
 
 // 64-lane helpers ----------------------------------------------------------

@@ -63,38 +63,55 @@ vsa_findsufboundaries(const DevIndex<IDX> &ix, uint32_t maxlcp,
   }
 }
 
-template <typename IDX, bool KEYED>
+template <typename IDX, bool DEEP>
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_complete_search(const DevIndex<IDX> ix, const DevQueries qs,
                   uint64_t qlimit, uint64_t *__restrict__ outleft,
                   uint64_t *__restrict__ outcount)
 {
   const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const bool active = q < qlimit;
+  const uint8_t *pattern = qs.symbols;
+  uint32_t plen = 0, maxlcp = 0;
+  uint64_t witness = 0, l = 0, count = 0;
+  bool have = false;
 
-  if (q >= qlimit)
+  if (active)
   {
-    return;
+    pattern = qs.symbols + qs.start[q];
+    plen = (uint32_t) qs.length[q];
   }
-  const uint8_t *pattern = qs.symbols + qs.start[q];
-  const uint32_t plen = (uint32_t) qs.length[q];
-  uint64_t vleft, vright, l = 0, count = 0;
-
-  if (vsa_bucket(ix, pattern, vleft, vright))
+  if constexpr (DEEP)
   {
-    uint32_t maxlcp;
-    uint64_t witness, r;
-
-    vsa_findmaxprefixlen<IDX, KEYED>(ix, vleft, vright, ix.pl, pattern, plen,
-                                     maxlcp, witness);
-    if (maxlcp >= plen)
+    const int st = vsa_locate_deep(ix, active, pattern, plen, maxlcp, witness);
+    if (st == VSA_LOC_SLOW)
     {
-      vsa_findsufboundaries<IDX, KEYED>(ix, maxlcp, witness, plen, vleft,
-                                        vright, l, r);
-      count = r - l + 1;
+      have = vsa_locate_reference(ix, pattern, plen, maxlcp, witness);
+    } else
+    {
+      have = st == VSA_LOC_FOUND;
+    }
+  } else
+  {
+    if (active)
+    {
+      have = vsa_locate_reference(ix, pattern, plen, maxlcp, witness);
     }
   }
-  outleft[q] = l;
-  outcount[q] = count;
+  if (have && maxlcp >= plen)
+  {
+    // the widening stops where lcp < plen, which every bucket boundary
+    // satisfies (lcp < prefixlength <= plen): no need for the bucket here
+    uint64_t r;
+    vsa_findsufboundaries<IDX, DEEP>(ix, maxlcp, witness, plen, 0, ix.n, l,
+                                     r);
+    count = r - l + 1;
+  }
+  if (active)
+  {
+    outleft[q] = l;
+    outcount[q] = count;
+  }
 }
 
 // processfinalexactmatchinterval, Vmengine/exactcompl.c:142-166, for all
@@ -272,7 +289,36 @@ vsa_decode_workitem(const DevQueries &qs, const uint64_t *__restrict__ base,
   }
 }
 
-template <typename IDX, bool MUM, bool KEYED>
+// [l, r] = all suffixes that share maxlcp symbols with the query, given one
+// of them: neighbours in the suffix array whose lcp is >= maxlcp
+template <typename IDX, bool KEYED>
+__device__ __forceinline__ void
+vsa_maxlcp_interval(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t w,
+                    uint64_t &l, uint64_t &r)
+{
+  for (l = w; l > 0; l--)
+  {
+    const uint64_t v = (maxlcp < 255)
+                           ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, l)
+                           : vsa_evallcp(ix, l);
+    if (v < maxlcp)
+    {
+      break;
+    }
+  }
+  for (r = w; r < ix.n; r++)
+  {
+    const uint64_t v = (maxlcp < 255)
+                           ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, r + 1)
+                           : vsa_evallcp(ix, r + 1);
+    if (v < maxlcp)
+    {
+      break;
+    }
+  }
+}
+
+template <typename IDX, bool MUM, bool DEEP>
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
                const uint64_t *__restrict__ base, uint32_t perquery,
@@ -282,43 +328,66 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
 {
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
   const bool active = t < nitems;
-  uint32_t c = 0, maxlcp = 0, off = 0;
+  uint32_t c = 0, maxlcp = 0, off = 0, remaining = 0;
   uint64_t witness = 0, q = 0;
   uint8_t leftchar = (uint8_t) VSA_SEPARATOR;
-  bool found = false;
+  const uint8_t *qptr = qs.symbols;
+  bool have = false, refwitness = true;
 
   if (active)
   {
     vsa_decode_workitem(qs, base, perquery, t, q, off);
-    const uint8_t *qptr = qs.symbols + qs.start[q] + off;
-    const uint32_t remaining = (uint32_t) qs.length[q] - off;
-    uint64_t vleft, vright;
-
+    qptr = qs.symbols + qs.start[q] + off;
+    remaining = (uint32_t) qs.length[q] - off;
     if (off > 0)
     {
       leftchar = qptr[-1];
     }
-    if (vsa_bucket(ix, qptr, vleft, vright))
+  }
+  if constexpr (DEEP)
+  {
+    const int st = vsa_locate_deep(ix, active, qptr, remaining, maxlcp,
+                                   witness);
+    if (st == VSA_LOC_SLOW)
     {
-      vsa_findmaxprefixlen<IDX, KEYED>(ix, vleft, vright, ix.pl, qptr,
-                                       remaining, maxlcp, witness);
-      found = maxlcp >= searchlength;
+      have = vsa_locate_reference(ix, qptr, remaining, maxlcp, witness);
+    } else
+    {
+      have = st == VSA_LOC_FOUND;
+      refwitness = false;
     }
-    if (found)
+  } else
+  {
+    if (active)
     {
-      if (MUM)
+      have = vsa_locate_reference(ix, qptr, remaining, maxlcp, witness);
+    }
+  }
+  const bool found = have && maxlcp >= searchlength;
+  if (found)
+  {
+    if (MUM)
+    {
+      c = (vsa_mum_candidate<IDX, DEEP>(ix, maxlcp, witness) &&
+           vsa_leftmaximal(ix, vsa_sufstart<IDX, DEEP>(ix, witness),
+                           leftchar))
+              ? 1u
+              : 0u;
+    } else
+    {
+      if (!refwitness)
       {
-        c = (vsa_mum_candidate<IDX, KEYED>(ix, maxlcp, witness) &&
-             vsa_leftmaximal(ix, vsa_sufstart<IDX, KEYED>(ix, witness),
-                             leftchar))
-                ? 1u
-                : 0u;
-      } else
-      {
-        c = vsa_mem_walk<IDX, KEYED, false>(ix, maxlcp, witness, leftchar,
-                                            searchlength, q, off, nullptr,
-                                            nullptr, t);
+        // the enumeration starts at the reference's witness
+        uint64_t l, r, vleft, vright;
+        vsa_maxlcp_interval<IDX, DEEP>(ix, maxlcp, witness, l, r);
+        if (l != r && vsa_bucket(ix, qptr, vleft, vright))
+        {
+          witness = vsa_reference_witness(vleft, vright, l, r);
+        }
       }
+      c = vsa_mem_walk<IDX, DEEP, false>(ix, maxlcp, witness, leftchar,
+                                         searchlength, q, off, nullptr,
+                                         nullptr, t);
     }
   }
   // all 64 lanes arrive here
@@ -329,16 +398,16 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
     {
       vsa_match m;
       m.length = maxlcp;
-      m.dbstart = vsa_sufstart<IDX, KEYED>(ix, witness);
+      m.dbstart = vsa_sufstart<IDX, DEEP>(ix, witness);
       m.queryseq = q + qs.seqoffset;
       m.querystart = off;
       out[mybase] = m;
       outkey[mybase] = t;
     } else
     {
-      vsa_mem_walk<IDX, KEYED, true>(ix, maxlcp, witness, leftchar,
-                                     searchlength, q + qs.seqoffset, off,
-                                     out + mybase, outkey + mybase, t);
+      vsa_mem_walk<IDX, DEEP, true>(ix, maxlcp, witness, leftchar,
+                                    searchlength, q + qs.seqoffset, off,
+                                    out + mybase, outkey + mybase, t);
     }
   }
 }
@@ -681,10 +750,18 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   tall.start();
   VSA_HIP(hipMemsetAsync(count.as<uint64_t>() + qlimit, 0, 8, stream));
   tsearch.start();
-  if (ix.esa8 != nullptr)
+  if constexpr (sizeof(IDX) == 4)
   {
-    k_complete_search<IDX, true><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
-        ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+    if (ix.esa8 != nullptr)
+    {
+      k_complete_search<IDX, true><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+          ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+    } else
+    {
+      k_complete_search<IDX, false>
+          <<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+              ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+    }
   } else
   {
     k_complete_search<IDX, false><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
@@ -875,16 +952,23 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           ix, qs, dbase, perquery, nitems, searchlength,                      \
           out.as<vsa_match>(), keys.as<uint64_t>(), capacity,                 \
           cursor.as<unsigned long long>())
-    if (ix.esa8 != nullptr)
+    // deep locate needs the deep prefix to fit into every search
+    bool deep = false;
+    if constexpr (sizeof(IDX) == 4)
     {
-      if (domum)
+      deep = ix.esa8 != nullptr && searchlength >= ix.D;
+      if (deep)
       {
-        VSA_LAUNCH_QUERY(true, true);
-      } else
-      {
-        VSA_LAUNCH_QUERY(false, true);
+        if (domum)
+        {
+          VSA_LAUNCH_QUERY(true, true);
+        } else
+        {
+          VSA_LAUNCH_QUERY(false, true);
+        }
       }
-    } else
+    }
+    if (!deep)
     {
       if (domum)
       {
@@ -1026,7 +1110,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
 
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
-            const uint8_t *__restrict__ lcp, uint64_t count, uint32_t pl,
+            const uint8_t *__restrict__ lcp, uint64_t count, uint32_t D,
             uint64_t *__restrict__ esa8)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
@@ -1035,7 +1119,7 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
     return;
   }
   const uint32_t s = suf[j];
-  const uint8_t *t = tis + (uint64_t) s + pl; // padded with 0xFF behind n
+  const uint8_t *t = tis + (uint64_t) s + D; // padded with 0xFF behind n
   uint64_t key = 0, flag = 0;
 #pragma unroll
   for (uint32_t k = 0; k < VSA_KEYSYMS; k++)
@@ -1059,19 +1143,51 @@ int vsa_index_make_esa8(vsa_index *ix)
     (void) hipFree(ix->esa8);
     ix->esa8 = nullptr;
   }
-  if (ix->numofchars > 4 || ix->isize != 4 || ix->bck == nullptr ||
+  if (ix->bck2 != nullptr)
+  {
+    (void) hipFree(ix->bck2);
+    ix->bck2 = nullptr;
+  }
+  if (ix->numofchars != 4 || ix->isize != 4 || ix->bck == nullptr ||
       (off != nullptr && strcmp(off, "1") == 0))
   {
     return 0;
   }
-  // the key window may reach VSA_KEYSYMS symbols past the text end
-  static_assert(VSA_TIS_BACKPAD >= VSA_KEYSYMS + 8, "text pad too small");
-  const uint64_t count = ix->n + 1;
+  // deep prefix: about one to four suffixes per bucket, never shorter than
+  // the reference's prefixlength, table (8 * 4^D bytes) never above ~8n
+  uint32_t D = 1;
+  while (D < 15 && (1ull << (2 * (D + 1))) <= ix->n)
+  {
+    D++;
+  }
+  if (D < ix->pl)
+  {
+    D = ix->pl;
+  }
+  const char *fd = getenv("VSA_DEEP_PREFIX");
+  if (fd != nullptr && atoi(fd) >= (int) ix->pl && atoi(fd) <= 15)
+  {
+    D = (uint32_t) atoi(fd);
+  }
+  if (D > 15)
+  {
+    return 0;
+  }
+  static_assert(VSA_TIS_BACKPAD >= 15 + VSA_KEYSYMS + 8, "text pad too small");
+  ix->D = D;
+  const uint64_t count = ix->n + 1, ncodes = 1ull << (2 * D);
+  VSA_HIP(hipMalloc((void **) &ix->bck2, 2 * ncodes * 4 + 16));
   VSA_HIP(hipMalloc((void **) &ix->esa8, count * 8 + 64));
-  ix->device_bytes += count * 8;
+  ix->device_bytes += count * 8 + 2 * ncodes * 4;
+  if (vsa_build_bucket_table(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
+                             (const uint32_t *) ix->suf, D, 4, ix->bck2,
+                             ix->stream))
+  {
+    return -100;
+  }
   k_make_esa8<<<gridfor(count), VSA_BLOCK, 0, ix->stream>>>(
       ix->tis_alloc + VSA_TIS_FRONTPAD, (const uint32_t *) ix->suf, ix->lcp,
-      count, ix->pl, ix->esa8);
+      count, D, ix->esa8);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(ix->stream));
   return 0;

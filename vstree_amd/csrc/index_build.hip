@@ -470,6 +470,50 @@ int maxscan_inplace(uint32_t *data, uint64_t count, hipStream_t stream)
   return 0;
 }
 
+} // namespace
+
+int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
+                           uint32_t pl, uint32_t numofchars, uint32_t *out,
+                           hipStream_t stream)
+{
+  DevBuf left, mid, temp;
+  uint64_t nc = 1;
+  for (uint32_t k = 0; k < pl; k++)
+  {
+    nc *= numofchars;
+  }
+  const uint64_t count = n + 1;
+  if (left.alloc((nc + 1) * 4) || mid.alloc(nc * 4))
+  {
+    return -100;
+  }
+  k_bck_init<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
+      left.as<uint32_t>(), mid.as<uint32_t>(), nc);
+  VSA_HIP(hipGetLastError());
+  k_bck_boundaries<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+      tis, n, sa, pl, numofchars, left.as<uint32_t>(), mid.as<uint32_t>());
+  VSA_HIP(hipGetLastError());
+  // suffix-min over the codes = inclusive min-scan on the reversed array
+  size_t tb = 0;
+  auto rin = rocprim::make_reverse_iterator(left.as<uint32_t>() + nc);
+  VSA_HIP(rocprim::inclusive_scan(nullptr, tb, rin, rin, (size_t) nc, MinOp(),
+                                  stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::inclusive_scan(temp.p, tb, rin, rin, (size_t) nc, MinOp(),
+                                  stream));
+  k_bck_finish<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
+      left.as<uint32_t>(), mid.as<uint32_t>(), nc, out);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+namespace
+{
+
 int build_tables(vsa_index *ix)
 {
   hipStream_t stream = ix->stream;
@@ -698,34 +742,10 @@ int build_tables(vsa_index *ix)
   }
 
   // B5: bck
+  if (vsa_build_bucket_table(tis, n, sa, ix->pl, ix->numofchars,
+                             (uint32_t *) ix->bck, stream))
   {
-    DevBuf left, mid, temp;
-    const uint64_t nc = ix->numofcodes;
-    if (left.alloc((nc + 1) * 4) || mid.alloc(nc * 4))
-    {
-      return -100;
-    }
-    k_bck_init<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
-        left.as<uint32_t>(), mid.as<uint32_t>(), nc);
-    VSA_HIP(hipGetLastError());
-    k_bck_boundaries<<<gridfor(count), VB_BLOCK, 0, stream>>>(
-        tis, n, sa, ix->pl, ix->numofchars, left.as<uint32_t>(),
-        mid.as<uint32_t>());
-    VSA_HIP(hipGetLastError());
-    // suffix-min over the codes = inclusive min-scan on the reversed array
-    size_t tb = 0;
-    auto rin = rocprim::make_reverse_iterator(left.as<uint32_t>() + nc);
-    VSA_HIP(rocprim::inclusive_scan(nullptr, tb, rin, rin, (size_t) nc,
-                                    MinOp(), stream));
-    if (temp.alloc(tb))
-    {
-      return -100;
-    }
-    VSA_HIP(rocprim::inclusive_scan(temp.p, tb, rin, rin, (size_t) nc,
-                                    MinOp(), stream));
-    k_bck_finish<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
-        left.as<uint32_t>(), mid.as<uint32_t>(), nc, (uint32_t *) ix->bck);
-    VSA_HIP(hipGetLastError());
+    return -100;
   }
 
   // B6: bwt

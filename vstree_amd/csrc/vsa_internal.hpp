@@ -54,14 +54,15 @@ struct DevIndex
   const IDX *llv;     // [2*nllv]
   const IDX *bck;     // [2*numofcodes]
   const uint8_t *bwt; // [n+1] or nullptr
-  // [n+1] or nullptr: per suffix {suf:32 | lcp byte:8 | key:22 | flag:1},
-  // key = the VSA_KEYSYMS symbols behind the first pl ones, 2 bits each,
-  // first symbol most significant; flag = a special symbol in that window.
-  // One 8-byte load answers most probes of the in-bucket search without
-  // touching the text (DNA alphabets with 32-bit suf only).
+  // Deep locate (esa_device.hpp), DNA alphabets with 32-bit suf only:
+  // esa8 [n+1] per suffix {suf:32 | lcp byte:8 | key:22 | flag:1}, key = the
+  // VSA_KEYSYMS symbols behind the first D ones, 2 bits each, first symbol
+  // most significant, flag = a special symbol in that window;
+  // bck2 [2*4^D] (left, mid) pairs like bck, for D >= pl symbols.
   const uint64_t *esa8;
+  const uint32_t *bck2;
   uint64_t n, nllv, numofcodes;
-  uint32_t pl, numofchars;
+  uint32_t pl, numofchars, D;
 };
 
 #define VSA_KEYSYMS 11u
@@ -79,7 +80,9 @@ struct vsa_index
   uint8_t *tis_alloc; // allocation; text starts at tis_alloc + FRONTPAD
   void *suf, *llv, *bck;
   uint8_t *lcp, *bwt;
-  uint64_t *esa8; // search array, see DevIndex (may be nullptr)
+  uint64_t *esa8; // deep-locate tables, see DevIndex (may be nullptr)
+  uint32_t *bck2;
+  uint32_t D;
   uint64_t querysepposition;
   int hasindexedqueries;
   uint64_t device_bytes;
@@ -95,6 +98,8 @@ struct vsa_index
     v.bck = (const IDX *) bck;
     v.bwt = bwt;
     v.esa8 = esa8;
+    v.bck2 = bck2;
+    v.D = D;
     v.n = n;
     v.nllv = nllv;
     v.numofcodes = numofcodes;
@@ -153,9 +158,15 @@ static inline DevQueries devqueries(const vsa_queries *q)
 
 int vsa_set_device(int device);
 
-// builds the keyed search array from tis/suf/lcp (esa_search.hip); a no-op
-// for alphabets beyond 4 symbols, 64-bit tables or VSA_NO_ESA8=1
+// builds the deep-locate tables bck2/esa8 from tis/suf/lcp (esa_search.hip);
+// a no-op for alphabets beyond 4 symbols, 64-bit tables or VSA_NO_ESA8=1
 int vsa_index_make_esa8(vsa_index *ix);
+
+// (left, mid) bucket boundaries for the first pl symbols, from the sorted
+// suffixes (index_build.hip): out[2*numofchars^pl] on the device
+int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
+                           uint32_t pl, uint32_t numofchars, uint32_t *out,
+                           hipStream_t stream);
 
 // device tables of the given shape, contents undefined (api.hip)
 int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
