@@ -359,11 +359,17 @@ enum
 // pass active = false): the key search runs a wavefront-uniform number of
 // rounds.  On VSA_LOC_FOUND: maxlcp = the maximal matched length over the
 // whole index, w = a suffix-array index attaining it.
+__device__ __forceinline__ uint64_t vsa_ld_entry(const uint64_t *p, bool nt)
+{
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
+
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
                 uint64_t &w)
 {
+  const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
   uint32_t dl = 0, cnt = 0, qkey = 0, limit = 0;
@@ -411,9 +417,11 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
         limit = VSA_KEYSYMS;
       }
       // (left, mid) of the deep bucket: one 8-byte load
-      const uint2 b = *reinterpret_cast<const uint2 *>(ix.bck2 + 2 * code);
-      dl = b.x;
-      cnt = (b.y > b.x) ? b.y - b.x : 0;
+      const uint64_t b = vsa_ld_entry(
+          reinterpret_cast<const uint64_t *>(ix.bck2) + code, nt);
+      dl = (uint32_t) b;
+      const uint32_t dm = (uint32_t) (b >> 32);
+      cnt = (dm > dl) ? dm - dl : 0;
       state = (cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
     }
   }
@@ -438,7 +446,7 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     if (lo < hi)
     {
       const uint32_t mid = (lo + hi) >> 1;
-      const uint64_t e = ix.esa8[(uint64_t) dl + mid];
+      const uint64_t e = vsa_ld_entry(ix.esa8 + (uint64_t) dl + mid, nt);
       flagged = flagged || (e & VSA_KEYFLAG) != 0;
       const uint32_t tk = ((uint32_t) (e >> VSA_KEYSHIFT) & VSA_KEYMASK) >>
                           (2 * (VSA_KEYSYMS - limit));
@@ -463,15 +471,15 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     hasnext = lo + 1 < cnt;
     if (haspred)
     {
-      epred = ix.esa8[base - 1];
+      epred = vsa_ld_entry(ix.esa8 + base - 1, nt);
     }
     if (hassucc)
     {
-      esucc = ix.esa8[base];
+      esucc = vsa_ld_entry(ix.esa8 + base, nt);
     }
     if (hasnext)
     {
-      enext = ix.esa8[base + 1];
+      enext = vsa_ld_entry(ix.esa8 + base + 1, nt);
     }
     flagged = flagged || (haspred && (epred & VSA_KEYFLAG) != 0) ||
               (hassucc && (esucc & VSA_KEYFLAG) != 0);

@@ -1175,6 +1175,8 @@ int vsa_index_make_esa8(vsa_index *ix)
   }
   static_assert(VSA_TIS_BACKPAD >= 15 + VSA_KEYSYMS + 8, "text pad too small");
   ix->D = D;
+  const char *tune = getenv("VSA_TUNE");
+  ix->tune = tune != nullptr ? (uint32_t) atoi(tune) : 0;
   const uint64_t count = ix->n + 1, ncodes = 1ull << (2 * D);
   VSA_HIP(hipMalloc((void **) &ix->bck2, 2 * ncodes * 4 + 16));
   VSA_HIP(hipMalloc((void **) &ix->esa8, count * 8 + 64));

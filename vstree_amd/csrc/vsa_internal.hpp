@@ -63,6 +63,7 @@ struct DevIndex
   const uint32_t *bck2;
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars, D;
+  uint32_t tune; // experiment switches (VSA_TUNE): bit0 = nontemporal probes
 };
 
 #define VSA_KEYSYMS 11u
@@ -82,7 +83,7 @@ struct vsa_index
   uint8_t *lcp, *bwt;
   uint64_t *esa8; // deep-locate tables, see DevIndex (may be nullptr)
   uint32_t *bck2;
-  uint32_t D;
+  uint32_t D, tune;
   uint64_t querysepposition;
   int hasindexedqueries;
   uint64_t device_bytes;
@@ -100,6 +101,7 @@ struct vsa_index
     v.esa8 = esa8;
     v.bck2 = bck2;
     v.D = D;
+    v.tune = tune;
     v.n = n;
     v.nllv = nllv;
     v.numofcodes = numofcodes;
