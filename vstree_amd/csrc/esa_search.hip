@@ -23,6 +23,8 @@
 #include <rocprim/rocprim.hpp>
 
 #define VSA_BLOCK 256
+#define VSA_CURSOR_STRIDE 8   // uint64 words: one cursor per 64-byte line
+#define VSA_CURSOR_SHARDS 2048 // power of two
 
 // ---------------------------------------------------------------------------
 // K1: exact complete matches (Vmengine/exactcompl.c:168-216)
@@ -324,7 +326,8 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
                const uint64_t *__restrict__ base, uint32_t perquery,
                uint64_t nitems, uint32_t searchlength,
                vsa_match *__restrict__ out, uint64_t *__restrict__ outkey,
-               uint64_t capacity, unsigned long long *__restrict__ cursor)
+               uint64_t shardcap, uint32_t shardmask,
+               unsigned long long *__restrict__ cursors)
 {
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
   const bool active = t < nitems;
@@ -390,10 +393,16 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
                                          nullptr, t);
     }
   }
-  // all 64 lanes arrive here
-  const uint64_t mybase = vsa_wave_reserve(cursor, c);
-  if (c > 0 && mybase + c <= capacity)
+  // all 64 lanes arrive here.  Output space comes from one of many cursors
+  // (one 64-byte line each, picked by workgroup number): a single cursor
+  // word takes ~11 ns per returning atomic, which for 10^7 wavefronts is
+  // longer than the whole search.  The regions are compacted afterwards.
+  const uint32_t shard = blockIdx.x & shardmask;
+  const uint64_t inshard =
+      vsa_wave_reserve(cursors + (uint64_t) shard * VSA_CURSOR_STRIDE, c);
+  if (c > 0 && inshard + c <= shardcap)
   {
+    const uint64_t mybase = (uint64_t) shard * shardcap + inshard;
     if (MUM)
     {
       vsa_match m;
@@ -409,6 +418,24 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
                                     searchlength, q + qs.seqoffset, off,
                                     out + mybase, outkey + mybase, t);
     }
+  }
+}
+
+// gathers the filled part of every cursor region into one dense list
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_compact_shards(const vsa_match *__restrict__ in,
+                 const uint64_t *__restrict__ inkey, uint64_t shardcap,
+                 const unsigned long long *__restrict__ cursors,
+                 const uint64_t *__restrict__ offsets,
+                 vsa_match *__restrict__ out, uint64_t *__restrict__ outkey)
+{
+  const uint32_t shard = blockIdx.x;
+  const uint64_t count = cursors[(uint64_t) shard * VSA_CURSOR_STRIDE],
+                 src = (uint64_t) shard * shardcap, dst = offsets[shard];
+  for (uint64_t i = threadIdx.x; i < count; i += VSA_BLOCK)
+  {
+    out[dst + i] = in[src + i];
+    outkey[dst + i] = inkey[src + i];
   }
 }
 
@@ -927,31 +954,37 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     return 0;
   }
-  if (cursor.alloc(8))
+  const uint32_t nshards = VSA_CURSOR_SHARDS;
+  std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
+  DevBuf doff, rawout, rawkeys;
+  if (cursor.alloc(hcur.size() * 8) || doff.alloc(nshards * 8))
   {
     return -100;
   }
   // first guess: MUM modes report at most one match per work-item but
   // typically about one per query; MEM is unbounded.  The kernel counts what
-  // it needs and never writes past capacity; on overflow run again.
-  uint64_t capacity = std::max<uint64_t>(queries->nq * 2 + 1024, 1 << 16);
-  uint64_t needed = 0;
+  // it needs and never writes past a region's capacity; on overflow of any
+  // region run again with regions of the size that was asked for.
+  uint64_t shardcap =
+      std::max<uint64_t>((queries->nq * 2 / nshards) * 5 / 4 + 64, 256);
+  uint64_t needed = 0, maxshard = 0;
   double searchms = 0;
   tall.start();
   for (int attempt = 0; attempt < 2; attempt++)
   {
-    if (out.alloc(capacity * sizeof(vsa_match)) || keys.alloc(capacity * 8))
+    if (rawout.alloc(nshards * shardcap * sizeof(vsa_match)) ||
+        rawkeys.alloc(nshards * shardcap * 8))
     {
       return -100;
     }
-    VSA_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
     tsearch.start();
 #define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
   k_query_search<IDX, MUMFLAG, KEYFLAG>                                       \
       <<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(                            \
           ix, qs, dbase, perquery, nitems, searchlength,                      \
-          out.as<vsa_match>(), keys.as<uint64_t>(), capacity,                 \
-          cursor.as<unsigned long long>())
+          rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
+          nshards - 1, cursor.as<unsigned long long>())
     // deep locate needs the deep prefix to fit into every search
     bool deep = false;
     if constexpr (sizeof(IDX) == 4)
@@ -981,21 +1014,43 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
 #undef VSA_LAUNCH_QUERY
     tsearch.stop();
     VSA_HIP(hipGetLastError());
-    VSA_HIP(hipMemcpyAsync(&needed, cursor.p, 8, hipMemcpyDeviceToHost,
-                           stream));
+    VSA_HIP(hipMemcpyAsync(hcur.data(), cursor.p, hcur.size() * 8,
+                           hipMemcpyDeviceToHost, stream));
     VSA_HIP(hipStreamSynchronize(stream));
     searchms += tsearch.ms();
-    if (needed <= capacity)
+    needed = maxshard = 0;
+    for (uint32_t sh = 0; sh < nshards; sh++)
+    {
+      const uint64_t cnt = hcur[(uint64_t) sh * VSA_CURSOR_STRIDE];
+      hoff[sh] = needed;
+      needed += cnt;
+      maxshard = std::max(maxshard, cnt);
+    }
+    if (maxshard <= shardcap)
     {
       break;
     }
-    capacity = needed;
+    shardcap = maxshard;
   }
-  if (needed > capacity)
+  if (maxshard > shardcap)
   {
     VSA_ERROR("match buffer overflow: %llu > %llu",
-              (unsigned long long) needed, (unsigned long long) capacity);
+              (unsigned long long) maxshard, (unsigned long long) shardcap);
     return -5;
+  }
+  if (needed > 0)
+  {
+    if (out.alloc(needed * sizeof(vsa_match)) || keys.alloc(needed * 8))
+    {
+      return -100;
+    }
+    VSA_HIP(hipMemcpyAsync(doff.p, hoff.data(), nshards * 8,
+                           hipMemcpyHostToDevice, stream));
+    k_compact_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
+        rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
+        cursor.as<unsigned long long>(), doff.as<uint64_t>(),
+        out.as<vsa_match>(), keys.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
   }
   res->stats.candidates = domum ? needed : 0;
   if (domum && !domumcand)
