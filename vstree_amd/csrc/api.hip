@@ -429,6 +429,11 @@ extern "C" int vsa_queries_from_host(const uint8_t *symbols,
   q->start = q->length = nullptr;
   q->hlength.assign(length, length + nq);
   summarise_lengths(q);
+  q->dense = q->uniform;
+  for (uint64_t i = 0; q->dense && i < nq; i++)
+  {
+    q->dense = start[i] == i * length[0];
+  }
   *queries = q;
   VSA_HIP(hipMalloc((void **) &q->symbols, nsymbols + VSA_QUERY_BACKPAD));
   VSA_HIP(hipMalloc((void **) &q->start, (nq + 1) * 8));
@@ -480,6 +485,7 @@ extern "C" int vsa_queries_from_device(const void *device_symbols,
   q->start = q->length = nullptr;
   q->hlength.assign(nq, (uint64_t) m);
   summarise_lengths(q);
+  q->dense = q->uniform;
   *queries = q;
   VSA_HIP(hipMalloc((void **) &q->symbols,
                     q->nsymbols + VSA_QUERY_BACKPAD));

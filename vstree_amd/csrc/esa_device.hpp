@@ -91,6 +91,61 @@ __device__ __forceinline__ int vsa_compare(const DevIndex<IDX> &ix,
   }
 }
 
+// The same comparison, 32 symbols per round trip: used where all lanes of a
+// wavefront extend a long match at the same time, so that the number of
+// dependent memory steps, not the number of loads, sets the pace.
+template <typename IDX>
+__device__ __forceinline__ int vsa_compare32(const DevIndex<IDX> &ix,
+                                             uint64_t sufstart,
+                                             const uint8_t *query,
+                                             uint32_t querylen,
+                                             uint32_t &lcplen)
+{
+  const uint8_t *t = ix.tis + sufstart;
+  uint32_t l = lcplen;
+
+  for (;;)
+  {
+    if (l >= querylen)
+    {
+      lcplen = querylen;
+      return 0;
+    }
+    uint64_t a[4], b[4], m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      a[k] = vsa_load8(query + l + 8 * k);
+      b[k] = vsa_load8(t + l + 8 * k);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      m[k] = (a[k] ^ b[k]) | vsa_specialmask(a[k]) | vsa_specialmask(b[k]);
+    }
+    if ((m[0] | m[1] | m[2] | m[3]) == 0)
+    {
+      l += 32;
+      continue;
+    }
+    int k = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
+    const uint64_t mm = m[0] ? m[0] : (m[1] ? m[1] : (m[2] ? m[2] : m[3]));
+    const uint64_t aa = m[0] ? a[0] : (m[1] ? a[1] : (m[2] ? a[2] : a[3]));
+    const uint64_t bb = m[0] ? b[0] : (m[1] ? b[1] : (m[2] ? b[2] : b[3]));
+    const uint32_t j = (uint32_t) __builtin_ctzll(mm) >> 3;
+    l += 8 * k + j;
+    if (l >= querylen)
+    {
+      lcplen = querylen;
+      return 0;
+    }
+    lcplen = l;
+    const int qa = (int) ((aa >> (8 * j)) & 0xFF),
+              tb = (int) ((bb >> (8 * j)) & 0xFF);
+    return (qa == tb) ? -1 : qa - tb;
+  }
+}
+
 // table accessors: esa8 carries suf and the lcp byte next to each other
 template <typename IDX, bool KEYED>
 __device__ __forceinline__ uint64_t vsa_sufstart(const DevIndex<IDX> &ix,
@@ -364,10 +419,20 @@ __device__ __forceinline__ uint64_t vsa_ld_entry(const uint64_t *p, bool nt)
   return nt ? __builtin_nontemporal_load(p) : *p;
 }
 
+// what the deep locate knows about the located suffix w without further
+// memory traffic: its esa8 entry (start, lcp byte), the lcp byte of w+1 and
+// the text symbol in front of it
+struct DeepHit
+{
+  uint64_t ew;      // esa8[w]
+  uint32_t lcpnext; // lcp byte of entry w+1 (0 if w = n)
+  uint8_t leftsym;  // tis[suf[w]-1] (separator if suf[w] = 0)
+};
+
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
-                uint64_t &w)
+                uint64_t &w, DeepHit &hit)
 {
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
@@ -460,7 +525,9 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     }
   }
   // neighbours of the insertion point: pred = lo-1, succ = lo, and succ+1
-  // for the size of a tie; three independent loads
+  // for the size of a tie; three independent loads.  pred/succ/next are
+  // fetched by suffix-array index whether or not they lie in the bucket:
+  // their lcp bytes serve the uniqueness test of the located suffix.
   uint64_t epred = 0, esucc = 0, enext = 0;
   bool haspred = false, hassucc = false, hasnext = false;
   if (searching)
@@ -469,15 +536,15 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     haspred = lo > 0;
     hassucc = lo < cnt;
     hasnext = lo + 1 < cnt;
-    if (haspred)
+    if (base > 0)
     {
       epred = vsa_ld_entry(ix.esa8 + base - 1, nt);
     }
-    if (hassucc)
+    if (base <= ix.n)
     {
       esucc = vsa_ld_entry(ix.esa8 + base, nt);
     }
-    if (hasnext)
+    if (base + 1 <= ix.n)
     {
       enext = vsa_ld_entry(ix.esa8 + base + 1, nt);
     }
@@ -523,13 +590,25 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
         w = (uint64_t) dl + lo - 1;
         maxlcp = D + lp;
       }
+      if (state == VSA_LOC_FOUND)
+      {
+        const bool atsucc = w == (uint64_t) dl + lo;
+        hit.ew = atsucc ? esucc : epred;
+        hit.lcpnext = (uint32_t) ((atsucc ? enext : esucc) >> 32) & 0xFFu;
+      }
     }
+  }
+  // the symbol in front of the located suffix (left maximality) travels
+  // with the first text words: one round trip less.  Front pad = separator.
+  if (state == VSA_LOC_FOUND)
+  {
+    hit.leftsym = ix.tis[(int64_t) (hit.ew & 0xFFFFFFFFull) - 1];
   }
   // one text comparison for the lanes with a tie, all at the same time
   if (extend)
   {
     uint32_t lcplen = maxlcp;
-    (void) vsa_compare(ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
+    (void) vsa_compare32(ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
     maxlcp = lcplen;
   }
   return state;

@@ -80,12 +80,21 @@ k_complete_search(const DevIndex<IDX> ix, const DevQueries qs,
 
   if (active)
   {
-    pattern = qs.symbols + qs.start[q];
-    plen = (uint32_t) qs.length[q];
+    if (qs.dense)
+    {
+      pattern = qs.symbols + q * qs.uniformlen;
+      plen = qs.uniformlen;
+    } else
+    {
+      pattern = qs.symbols + qs.start[q];
+      plen = (uint32_t) qs.length[q];
+    }
   }
   if constexpr (DEEP)
   {
-    const int st = vsa_locate_deep(ix, active, pattern, plen, maxlcp, witness);
+    DeepHit hit;
+    const int st = vsa_locate_deep(ix, active, pattern, plen, maxlcp, witness,
+                                   hit);
     if (st == VSA_LOC_SLOW)
     {
       have = vsa_locate_reference(ix, pattern, plen, maxlcp, witness);
@@ -340,17 +349,26 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
   if (active)
   {
     vsa_decode_workitem(qs, base, perquery, t, q, off);
-    qptr = qs.symbols + qs.start[q] + off;
-    remaining = (uint32_t) qs.length[q] - off;
+    if (qs.dense)
+    {
+      qptr = qs.symbols + q * qs.uniformlen + off;
+      remaining = qs.uniformlen - off;
+    } else
+    {
+      qptr = qs.symbols + qs.start[q] + off;
+      remaining = (uint32_t) qs.length[q] - off;
+    }
     if (off > 0)
     {
       leftchar = qptr[-1];
     }
   }
+  DeepHit hit;
+  bool fast = false; // hit holds what the MUM test needs
   if constexpr (DEEP)
   {
     const int st = vsa_locate_deep(ix, active, qptr, remaining, maxlcp,
-                                   witness);
+                                   witness, hit);
     if (st == VSA_LOC_SLOW)
     {
       have = vsa_locate_reference(ix, qptr, remaining, maxlcp, witness);
@@ -358,6 +376,7 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
     {
       have = st == VSA_LOC_FOUND;
       refwitness = false;
+      fast = have && maxlcp < 255;
     }
   } else
   {
@@ -371,11 +390,26 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
   {
     if (MUM)
     {
-      c = (vsa_mum_candidate<IDX, DEEP>(ix, maxlcp, witness) &&
-           vsa_leftmaximal(ix, vsa_sufstart<IDX, DEEP>(ix, witness),
-                           leftchar))
-              ? 1u
-              : 0u;
+      if (fast)
+      {
+        // leftrightmaximaluniquematch (fquery.c:297-386) and PROCESSSUFFIX
+        // (fquery.c:54-81) on values already in registers
+        const uint32_t lcpw = (uint32_t) (hit.ew >> 32) & 0xFFu;
+        const uint64_t ss = hit.ew & 0xFFFFFFFFull;
+        const bool unique = (witness == 0 || lcpw < maxlcp) &&
+                            (witness + 1 > ix.n - 1 || hit.lcpnext < maxlcp);
+        c = (unique && (ss == 0 || VSA_ISSPECIAL(leftchar) ||
+                        leftchar != hit.leftsym))
+                ? 1u
+                : 0u;
+      } else
+      {
+        c = (vsa_mum_candidate<IDX, DEEP>(ix, maxlcp, witness) &&
+             vsa_leftmaximal(ix, vsa_sufstart<IDX, DEEP>(ix, witness),
+                             leftchar))
+                ? 1u
+                : 0u;
+      }
     } else
     {
       if (!refwitness)
@@ -407,7 +441,8 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
     {
       vsa_match m;
       m.length = maxlcp;
-      m.dbstart = vsa_sufstart<IDX, DEEP>(ix, witness);
+      m.dbstart = fast ? (hit.ew & 0xFFFFFFFFull)
+                       : vsa_sufstart<IDX, DEEP>(ix, witness);
       m.queryseq = q + qs.seqoffset;
       m.querystart = off;
       out[mybase] = m;

@@ -41,7 +41,7 @@ extern "C" char *vsa_errbuf();
 #define VSA_TIS_FRONTPAD 16
 #define VSA_TIS_BACKPAD 64
 // queries are compared 8 bytes at a time, too
-#define VSA_QUERY_BACKPAD 16
+#define VSA_QUERY_BACKPAD 64
 
 // Device view of one index; IDX = uint32_t while totallength+1 fits, else
 // uint64_t.  Passed to kernels by value.
@@ -123,6 +123,7 @@ struct vsa_queries
   uint64_t seqoffset; // added to queryseq of every match
   std::vector<uint64_t> hlength; // host copy (needed for ragged batches)
   bool uniform;                  // all lengths equal
+  bool dense;                    // uniform and start[i] = i * length
 };
 
 struct vsa_result
@@ -141,6 +142,7 @@ struct DevQueries
   const uint64_t *length;
   uint64_t nq;
   uint32_t uniformlen; // != 0: every query has this length
+  uint32_t dense;      // != 0: and query i starts at i * uniformlen
   uint64_t seqoffset;
 };
 
@@ -152,6 +154,7 @@ static inline DevQueries devqueries(const vsa_queries *q)
   d.length = q->length;
   d.nq = q->nq;
   d.seqoffset = q->seqoffset;
+  d.dense = (q->uniform && q->dense) ? 1u : 0u;
   d.uniformlen = (q->uniform && q->maxlength < 0xFFFFFFFFull)
                      ? (uint32_t) q->maxlength
                      : 0;
