@@ -170,6 +170,7 @@ typedef struct
   uint64_t candidates;     /* MUM candidates before the query-side filter */
   double search_kernel_ms; /* HIP-event time of the dominant search kernel */
   double total_device_ms;  /* HIP-event time of the whole call            */
+  double anchor_ms;        /* -mum: anchor pass + work list (0 if unused)  */
 } vsa_stats;
 
 uint64_t vsa_result_count(const vsa_result *result);

@@ -329,16 +329,18 @@ vsa_maxlcp_interval(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t w,
   }
 }
 
-template <typename IDX, bool MUM, bool DEEP>
-__global__ void __launch_bounds__(VSA_BLOCK)
+template <typename IDX, bool MUM, bool DEEP, int BLK>
+__global__ void __launch_bounds__(BLK)
 k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
                const uint64_t *__restrict__ base, uint32_t perquery,
-               uint64_t nitems, uint32_t searchlength,
+               const uint32_t *__restrict__ wlq,
+               const uint32_t *__restrict__ wloff, uint64_t nitems,
+               uint32_t searchlength,
                vsa_match *__restrict__ out, uint64_t *__restrict__ outkey,
                uint64_t shardcap, uint32_t shardmask,
                unsigned long long *__restrict__ cursors)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  uint64_t t = (uint64_t) blockIdx.x * BLK + threadIdx.x;
   const bool active = t < nitems;
   uint32_t c = 0, maxlcp = 0, off = 0, remaining = 0;
   uint64_t witness = 0, q = 0;
@@ -348,7 +350,17 @@ k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
 
   if (active)
   {
-    vsa_decode_workitem(qs, base, perquery, t, q, off);
+    if (wlq != nullptr)
+    {
+      // explicit work list (k_mum_anchor / k_expand_worklist); the sort key
+      // stays the number the work-item has in the full (query, offset) grid
+      q = wlq[t];
+      off = wloff[t];
+      t = q * perquery + off;
+    } else
+    {
+      vsa_decode_workitem(qs, base, perquery, t, q, off);
+    }
     if (qs.dense)
     {
       qptr = qs.symbols + q * qs.uniformlen + off;
@@ -471,6 +483,122 @@ k_compact_shards(const vsa_match *__restrict__ in,
   {
     out[dst + i] = in[src + i];
     outkey[dst + i] = inkey[src + i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MUM work reduction.  If the query suffix at offset j matches the text up to
+// the END of the query, no offset j' > j of that query can produce a MUM
+// candidate: its longest match is the rest of the query as well, and if that
+// match is unique in the index it is the one at (position + j' - j), whose
+// left neighbour is the matched query symbol, so the test of
+// leftrightmaximaluniquematch / PROCESSSUFFIX (Vmengine/fquery.c:54-81,
+// 297-386) rejects it; if it is not unique it is rejected as well.  (The
+// reference's own algorithm 2 exploits the same suffix-link structure,
+// kurtz/matchsub.c:400-491.)  So: locate the LAST offset of every query; if
+// it matches completely, walk that occurrence backwards through the text as
+// far as it agrees with the query -- down to offset m -- and only offsets
+// 0..m need a search.  Queries that match end to end cost 2 searches instead
+// of (length - l + 1).
+// ---------------------------------------------------------------------------
+
+template <typename IDX, bool DEEP>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_anchor(const DevIndex<IDX> ix, const DevQueries qs, uint32_t perquery,
+             uint32_t searchlength, uint32_t *__restrict__ count)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const bool active = q < qs.nq && perquery > 0;
+  const uint32_t lastoff = perquery > 0 ? perquery - 1 : 0;
+  const uint8_t *qstart = qs.symbols, *qptr = qs.symbols;
+  uint32_t maxlcp = 0;
+  uint64_t witness = 0, sufstart = 0;
+  bool have = false;
+
+  if (active)
+  {
+    qstart = qs.dense ? qs.symbols + q * qs.uniformlen
+                      : qs.symbols + qs.start[q];
+    qptr = qstart + lastoff;
+  }
+  if constexpr (DEEP)
+  {
+    DeepHit hit;
+    const int st = vsa_locate_deep(ix, active, qptr, searchlength, maxlcp,
+                                   witness, hit);
+    if (st == VSA_LOC_SLOW)
+    {
+      have = vsa_locate_reference(ix, qptr, searchlength, maxlcp, witness);
+      sufstart = have ? (uint64_t) ix.suf[witness] : 0;
+    } else
+    {
+      have = st == VSA_LOC_FOUND;
+      sufstart = hit.ew & 0xFFFFFFFFull;
+    }
+  } else
+  {
+    if (active)
+    {
+      have = vsa_locate_reference(ix, qptr, searchlength, maxlcp, witness);
+      sufstart = have ? (uint64_t) ix.suf[witness] : 0;
+    }
+  }
+  if (!active)
+  {
+    return;
+  }
+  uint32_t need = perquery;
+  if (have && maxlcp >= searchlength)
+  {
+    // walk backwards: query[lastoff-1-k] against text[sufstart-1-k]; the
+    // text has 0xFF in front of position 0, specials never match
+    uint32_t k = 0;
+    while (k < lastoff)
+    {
+      const uint32_t room = lastoff - k; // query symbols still available
+      if (room >= 8)
+      {
+        const uint64_t a = vsa_load8(qptr - k - 8),
+                       b = vsa_load8(ix.tis + sufstart - k - 8);
+        const uint64_t m = (a ^ b) | vsa_specialmask(a) | vsa_specialmask(b);
+        if (m != 0)
+        {
+          k += (uint32_t) __builtin_clzll(m) >> 3; // matching bytes from top
+          break;
+        }
+        k += 8;
+      } else
+      {
+        const uint8_t a = qptr[-(int64_t) k - 1],
+                      b = ix.tis[(int64_t) sufstart - (int64_t) k - 1];
+        if (a != b || VSA_ISSPECIAL(a))
+        {
+          break;
+        }
+        k++;
+      }
+    }
+    need = lastoff - k + 1; // offsets 0 .. lastoff-k
+  }
+  count[q] = need;
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_expand_worklist(const uint32_t *__restrict__ count,
+                  const uint64_t *__restrict__ wbase, uint64_t nq,
+                  uint32_t *__restrict__ wlq, uint32_t *__restrict__ wloff)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (q >= nq)
+  {
+    return;
+  }
+  const uint32_t c = count[q];
+  const uint64_t b = wbase[q];
+  for (uint32_t j = 0; j < c; j++)
+  {
+    wlq[b + j] = (uint32_t) q;
+    wloff[b + j] = j;
   }
 }
 
@@ -990,6 +1118,73 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     return 0;
   }
   const uint32_t nshards = VSA_CURSOR_SHARDS;
+  const int qblock = (int) ((index->tune >> 8) & 0xFFF); // experiment switch
+  bool deepok = false;
+  if constexpr (sizeof(IDX) == 4)
+  {
+    deepok = ix.esa8 != nullptr && searchlength >= ix.D;
+  }
+  // MUM modes over batches of equal-length queries: anchor pass + work list
+  DevBuf wcount, wbase, wlq, wloff, wtemp;
+  const uint32_t *dwlq = nullptr, *dwloff = nullptr;
+  uint64_t nwork = nitems;
+  double anchorms = 0;
+  if (domum && qs.uniformlen != 0 && perquery > 1 &&
+      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0)
+  {
+    const uint64_t nq = queries->nq;
+    Timer tanchor(stream);
+    if (wcount.alloc((nq + 1) * 4) || wbase.alloc((nq + 1) * 8))
+    {
+      return -100;
+    }
+    tanchor.start();
+    VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
+    if (deepok)
+    {
+      if constexpr (sizeof(IDX) == 4)
+      {
+        k_mum_anchor<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+            ix, qs, perquery, searchlength, wcount.as<uint32_t>());
+      }
+    } else
+    {
+      k_mum_anchor<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          ix, qs, perquery, searchlength, wcount.as<uint32_t>());
+    }
+    VSA_HIP(hipGetLastError());
+    size_t tb = 0;
+    auto widen = rocprim::make_transform_iterator(
+        wcount.as<uint32_t>(),
+        [] __device__(uint32_t v) { return (uint64_t) v; });
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, widen, wbase.as<uint64_t>(),
+                                    (uint64_t) 0, (size_t) (nq + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    if (wtemp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, widen, wbase.as<uint64_t>(),
+                                    (uint64_t) 0, (size_t) (nq + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    VSA_HIP(hipMemcpyAsync(&nwork, wbase.as<uint64_t>() + nq, 8,
+                           hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    if (wlq.alloc(nwork * 4) || wloff.alloc(nwork * 4))
+    {
+      return -100;
+    }
+    k_expand_worklist<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+        wcount.as<uint32_t>(), wbase.as<uint64_t>(), nq, wlq.as<uint32_t>(),
+        wloff.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+    tanchor.stop();
+    VSA_HIP(hipStreamSynchronize(stream));
+    anchorms = tanchor.ms();
+    dwlq = wlq.as<uint32_t>();
+    dwloff = wloff.as<uint32_t>();
+    res->stats.searches = nwork + nq;
+  }
   std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
   DevBuf doff, rawout, rawkeys;
   if (cursor.alloc(hcur.size() * 8) || doff.alloc(nshards * 8))
@@ -1014,17 +1209,34 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
     tsearch.start();
-#define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
-  k_query_search<IDX, MUMFLAG, KEYFLAG>                                       \
-      <<<gridfor(nitems), VSA_BLOCK, 0, stream>>>(                            \
-          ix, qs, dbase, perquery, nitems, searchlength,                      \
+#define VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, BLK)                              \
+  k_query_search<IDX, MUMFLAG, KEYFLAG, BLK>                                  \
+      <<<(unsigned int) ((nwork + BLK - 1) / BLK), BLK, 0, stream>>>(         \
+          ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>())
+#define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
+  do                                                                          \
+  {                                                                           \
+    if (qblock == 64)                                                         \
+    {                                                                         \
+      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 64);                               \
+    } else if (qblock == 128)                                                 \
+    {                                                                         \
+      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 128);                              \
+    } else if (qblock == 512)                                                 \
+    {                                                                         \
+      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 512);                              \
+    } else                                                                    \
+    {                                                                         \
+      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 256);                              \
+    }                                                                         \
+  } while (0)
     // deep locate needs the deep prefix to fit into every search
     bool deep = false;
     if constexpr (sizeof(IDX) == 4)
     {
-      deep = ix.esa8 != nullptr && searchlength >= ix.D;
+      deep = deepok;
       if (deep)
       {
         if (domum)
@@ -1047,6 +1259,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       }
     }
 #undef VSA_LAUNCH_QUERY
+#undef VSA_LAUNCH_QUERY_B
     tsearch.stop();
     VSA_HIP(hipGetLastError());
     VSA_HIP(hipMemcpyAsync(hcur.data(), cursor.p, hcur.size() * 8,
@@ -1120,6 +1333,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   VSA_HIP(hipStreamSynchronize(stream));
   res->stats.count = res->count;
   res->stats.search_kernel_ms = searchms;
+  res->stats.anchor_ms = anchorms;
   res->stats.total_device_ms = tall.ms();
   return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
 }
