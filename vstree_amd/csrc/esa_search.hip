@@ -1000,6 +1000,63 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
 // ---- K2 (+K4) pipeline ----
 
 // MUM candidates, any order -> MUMs in dbstart order
+// (max dbstart, max length) of a candidate list
+struct MaxPair
+{
+  uint64_t db, len;
+};
+
+struct MaxPairOf
+{
+  __device__ MaxPair operator()(const vsa_match &m) const
+  {
+    MaxPair p;
+    p.db = m.dbstart;
+    p.len = m.length;
+    return p;
+  }
+};
+
+struct MaxPairOp
+{
+  __device__ MaxPair operator()(const MaxPair &a, const MaxPair &b) const
+  {
+    MaxPair p;
+    p.db = a.db > b.db ? a.db : b.db;
+    p.len = a.len > b.len ? a.len : b.len;
+    return p;
+  }
+};
+
+// one key for "dbstart ascending, then length descending"
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_compositekeys(const vsa_match *__restrict__ cand, uint64_t n,
+                    unsigned int lenbits, uint64_t *__restrict__ key,
+                    uint32_t *__restrict__ idx)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    const uint64_t lenmask = (1ull << lenbits) - 1;
+    key[i] = (cand[i].dbstart << lenbits) | (lenmask - cand[i].length);
+    idx[i] = (uint32_t) i;
+  }
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_gather(const vsa_match *__restrict__ cand,
+             const uint32_t *__restrict__ idx, uint64_t n,
+             vsa_match *__restrict__ sorted, uint64_t *__restrict__ rightend)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    const vsa_match m = cand[idx[i]];
+    sorted[i] = m;
+    rightend[i] = m.dbstart + m.length - 1;
+  }
+}
+
 int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
                      DevBuf &mums, uint64_t *nmums)
 {
@@ -1008,33 +1065,96 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   {
     return 0;
   }
-  DevBuf k1, k2, kout, m2, ends, dbright, keep, temp, dcount;
-  if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || kout.alloc(ncand * 8) ||
-      m2.alloc(ncand * sizeof(vsa_match)) || ends.alloc(ncand * 8) ||
-      dbright.alloc(ncand * 8) || keep.alloc(ncand) || dcount.alloc(8))
+  DevBuf ends, dbright, keep, temp, dcount, sorted;
+  if (ends.alloc(ncand * 8) || dbright.alloc(ncand * 8) ||
+      keep.alloc(ncand) || dcount.alloc(sizeof(MaxPair)) ||
+      sorted.alloc(ncand * sizeof(vsa_match)))
   {
     return -100;
   }
-  // least significant key first: length descending, then stable by dbstart
-  k_mum_keys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-      cand.as<vsa_match>(), ncand, k1.as<uint64_t>(), k2.as<uint64_t>());
-  VSA_HIP(hipGetLastError());
-  if (sortbykey(k1.as<uint64_t>(), kout.as<uint64_t>(), cand.as<vsa_match>(),
-                m2.as<vsa_match>(), ncand, 64, stream))
+  // how many bits do dbstart and length need?
+  MaxPair mx;
   {
-    return -100;
+    size_t tb = 0;
+    auto in = rocprim::make_transform_iterator(cand.as<vsa_match>(),
+                                               MaxPairOf());
+    MaxPair init;
+    init.db = init.len = 0;
+    VSA_HIP(rocprim::reduce(nullptr, tb, in, dcount.as<MaxPair>(), init,
+                            (size_t) ncand, MaxPairOp(), stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::reduce(temp.p, tb, in, dcount.as<MaxPair>(), init,
+                            (size_t) ncand, MaxPairOp(), stream));
+    VSA_HIP(hipMemcpyAsync(&mx, dcount.p, sizeof mx, hipMemcpyDeviceToHost,
+                           stream));
+    VSA_HIP(hipStreamSynchronize(stream));
   }
-  k_mum_keys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-      m2.as<vsa_match>(), ncand, k1.as<uint64_t>(), k2.as<uint64_t>());
-  VSA_HIP(hipGetLastError());
-  if (sortbykey(k2.as<uint64_t>(), kout.as<uint64_t>(), m2.as<vsa_match>(),
-                cand.as<vsa_match>(), ncand, 64, stream))
+  const unsigned int lenbits = bitsfor(mx.len), dbbits = bitsfor(mx.db);
+  if (lenbits + dbbits <= 64 && ncand < 0xFFFFFFFFull)
   {
-    return -100;
+    // one radix sort of (composite key, index) over just the bits in use,
+    // then one gather
+    DevBuf k1, k2, i1, i2;
+    if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || i1.alloc(ncand * 4) ||
+        i2.alloc(ncand * 4))
+    {
+      return -100;
+    }
+    k_mum_compositekeys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        cand.as<vsa_match>(), ncand, lenbits, k1.as<uint64_t>(),
+        i1.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+    size_t tb = 0;
+    VSA_HIP(rocprim::radix_sort_pairs(
+        nullptr, tb, k1.as<uint64_t>(), k2.as<uint64_t>(), i1.as<uint32_t>(),
+        i2.as<uint32_t>(), (size_t) ncand, 0u, lenbits + dbbits, stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::radix_sort_pairs(
+        temp.p, tb, k1.as<uint64_t>(), k2.as<uint64_t>(), i1.as<uint32_t>(),
+        i2.as<uint32_t>(), (size_t) ncand, 0u, lenbits + dbbits, stream));
+    k_mum_gather<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        cand.as<vsa_match>(), i2.as<uint32_t>(), ncand,
+        sorted.as<vsa_match>(), ends.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
+  } else
+  {
+    // wide values: least significant key first (length descending), then a
+    // stable sort by dbstart
+    DevBuf k1, k2, kout;
+    if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || kout.alloc(ncand * 8))
+    {
+      return -100;
+    }
+    k_mum_keys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        cand.as<vsa_match>(), ncand, k1.as<uint64_t>(), k2.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
+    if (sortbykey(k1.as<uint64_t>(), kout.as<uint64_t>(),
+                  cand.as<vsa_match>(), sorted.as<vsa_match>(), ncand, 64,
+                  stream))
+    {
+      return -100;
+    }
+    k_mum_keys<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        sorted.as<vsa_match>(), ncand, k1.as<uint64_t>(), k2.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
+    if (sortbykey(k2.as<uint64_t>(), kout.as<uint64_t>(),
+                  sorted.as<vsa_match>(), cand.as<vsa_match>(), ncand, 64,
+                  stream))
+    {
+      return -100;
+    }
+    VSA_HIP(hipMemcpyAsync(sorted.p, cand.p, ncand * sizeof(vsa_match),
+                           hipMemcpyDeviceToDevice, stream));
+    k_mum_rightends<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        sorted.as<vsa_match>(), ncand, ends.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
   }
-  k_mum_rightends<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-      cand.as<vsa_match>(), ncand, ends.as<uint64_t>());
-  VSA_HIP(hipGetLastError());
   size_t tb = 0;
   VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
                                   dbright.as<uint64_t>(), (uint64_t) 0,
@@ -1049,7 +1169,7 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
                                   (size_t) ncand, rocprim::maximum<uint64_t>(),
                                   stream));
   k_mum_flags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-      cand.as<vsa_match>(), ends.as<uint64_t>(), dbright.as<uint64_t>(),
+      sorted.as<vsa_match>(), ends.as<uint64_t>(), dbright.as<uint64_t>(),
       ncand, keep.as<uint8_t>());
   VSA_HIP(hipGetLastError());
   if (mums.alloc(ncand * sizeof(vsa_match)))
@@ -1057,14 +1177,14 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
     return -100;
   }
   tb = 0;
-  VSA_HIP(rocprim::select(nullptr, tb, cand.as<vsa_match>(),
+  VSA_HIP(rocprim::select(nullptr, tb, sorted.as<vsa_match>(),
                           keep.as<uint8_t>(), mums.as<vsa_match>(),
                           dcount.as<uint64_t>(), (size_t) ncand, stream));
   if (temp.alloc(tb))
   {
     return -100;
   }
-  VSA_HIP(rocprim::select(temp.p, tb, cand.as<vsa_match>(),
+  VSA_HIP(rocprim::select(temp.p, tb, sorted.as<vsa_match>(),
                           keep.as<uint8_t>(), mums.as<vsa_match>(),
                           dcount.as<uint64_t>(), (size_t) ncand, stream));
   VSA_HIP(hipMemcpyAsync(nmums, dcount.p, 8, hipMemcpyDeviceToHost, stream));
