@@ -277,6 +277,9 @@ int vsa_device_malloc(uint64_t bytes, int device, void **ptr);
 int vsa_device_free(void *ptr, int device);
 int vsa_device_count(void);
 int vsa_device_synchronize(int device);
+/* temporaries and freed result lists are recycled inside the library; this
+   hands the cached device memory back to HIP */
+int vsa_device_trim(int device);
 /* measured device-to-device streaming read rate in GB/s (roofline
    denominator cross-check in bench.py) */
 int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);

@@ -108,6 +108,7 @@ def _load():
         "vsa_device_free": (I, [V, I]),
         "vsa_device_count": (I, []),
         "vsa_device_synchronize": (I, [I]),
+        "vsa_device_trim": (I, [I]),
         "vsa_measure_stream_read": (I, [U64, I, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():

@@ -595,7 +595,7 @@ extern "C" void vsa_result_free(vsa_result *r)
     return;
   }
   (void) hipSetDevice(r->device);
-  (void) hipFree(r->matches);
+  vsa_dev_free(r->matches);
   delete r;
 }
 

@@ -556,7 +556,27 @@ k_mum_anchor(const DevIndex<IDX> ix, const DevQueries qs, uint32_t perquery,
     while (k < lastoff)
     {
       const uint32_t room = lastoff - k; // query symbols still available
-      if (room >= 8)
+      if (room >= 32)
+      {
+        // 32 symbols per round trip, most recent first
+        uint64_t m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+          const uint64_t a = vsa_load8(qptr - k - 8 * (i + 1)),
+                         b = vsa_load8(ix.tis + sufstart - k - 8 * (i + 1));
+          m[i] = (a ^ b) | vsa_specialmask(a) | vsa_specialmask(b);
+        }
+        if ((m[0] | m[1] | m[2] | m[3]) == 0)
+        {
+          k += 32;
+          continue;
+        }
+        const int i = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
+        const uint64_t mm = m[0] ? m[0] : (m[1] ? m[1] : (m[2] ? m[2] : m[3]));
+        k += 8 * i + ((uint32_t) __builtin_clzll(mm) >> 3);
+        break;
+      } else if (room >= 8)
       {
         const uint64_t a = vsa_load8(qptr - k - 8),
                        b = vsa_load8(ix.tis + sufstart - k - 8);
@@ -775,20 +795,13 @@ struct DevBuf
   void *p = nullptr;
   ~DevBuf()
   {
-    if (p != nullptr)
-    {
-      (void) hipFree(p);
-    }
+    vsa_dev_free(p);
   }
   int alloc(size_t bytes)
   {
-    if (p != nullptr)
-    {
-      (void) hipFree(p);
-      p = nullptr;
-    }
-    VSA_HIP(hipMalloc(&p, bytes > 0 ? bytes : 16));
-    return 0;
+    vsa_dev_free(p);
+    p = nullptr;
+    return vsa_dev_alloc(&p, bytes > 0 ? bytes : 16);
   }
   template <typename T>
   T *as()

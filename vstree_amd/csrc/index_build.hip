@@ -38,28 +38,18 @@ struct DevBuf
   void *p = nullptr;
   ~DevBuf()
   {
-    if (p != nullptr)
-    {
-      (void) hipFree(p);
-    }
+    vsa_dev_free(p);
   }
   int alloc(size_t bytes)
   {
-    if (p != nullptr)
-    {
-      (void) hipFree(p);
-      p = nullptr;
-    }
-    VSA_HIP(hipMalloc(&p, bytes > 0 ? bytes : 16));
-    return 0;
+    vsa_dev_free(p);
+    p = nullptr;
+    return vsa_dev_alloc(&p, bytes > 0 ? bytes : 16);
   }
   void free()
   {
-    if (p != nullptr)
-    {
-      (void) hipFree(p);
-      p = nullptr;
-    }
+    vsa_dev_free(p);
+    p = nullptr;
   }
   template <typename T>
   T *as()

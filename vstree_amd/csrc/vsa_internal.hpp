@@ -38,7 +38,7 @@ extern "C" char *vsa_errbuf();
 // at the first special symbol, and position totallength.. holds 0xFF, which
 // reproduces "sptr >= sentinel => retcode = -1" (kurtz/maxpref.c:57-61)
 // without a bounds test; 8-byte loads may run 7 bytes past it.
-#define VSA_TIS_FRONTPAD 16
+#define VSA_TIS_FRONTPAD 64
 #define VSA_TIS_BACKPAD 64
 // queries are compared 8 bytes at a time, too
 #define VSA_QUERY_BACKPAD 64
@@ -162,6 +162,11 @@ static inline DevQueries devqueries(const vsa_queries *q)
 }
 
 int vsa_set_device(int device);
+
+// recycled device memory for temporaries and result lists (devmem.hip)
+int vsa_dev_alloc(void **ptr, size_t bytes);
+void vsa_dev_free(void *ptr);
+void vsa_dev_trim();
 
 // builds the deep-locate tables bck2/esa8 from tis/suf/lcp (esa_search.hip);
 // a no-op for alphabets beyond 4 symbols, 64-bit tables or VSA_NO_ESA8=1
