@@ -494,11 +494,44 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   // only the first `limit` key symbols of the query exist
   const uint32_t qk = qkey >> (2 * (VSA_KEYSYMS - limit));
 
-  // lower bound on keys: ins = number of bucket entries whose key is smaller
-  // than the query's.  Trip count = that of the largest bucket in the
-  // wavefront, so the lanes stay converged.
-  uint32_t lo = 0, hi = searching ? cnt : 0;
+  // Buckets of up to four suffixes (nearly all of them: the deep prefix is
+  // chosen so that a bucket holds about one) are fetched whole, together
+  // with the entry behind them, in one round trip: five independent loads.
+  const bool small = searching && cnt <= 4;
+  const uint32_t ksh = 2 * (VSA_KEYSYMS - limit);
+  uint64_t e[5] = {0, 0, 0, 0, 0};
+  if (small)
+  {
+#pragma unroll
+    for (uint32_t i = 0; i < 5; i++)
+    {
+      if ((uint64_t) dl + i <= ix.n)
+      {
+        e[i] = vsa_ld_entry(ix.esa8 + (uint64_t) dl + i, nt);
+      }
+    }
+  }
+  // lower bound on keys: lo = number of bucket entries whose key is smaller
+  // than the query's
+  uint32_t lo = 0;
   bool flagged = false;
+  if (small)
+  {
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+    {
+      if (i < cnt)
+      {
+        flagged = flagged || (e[i] & VSA_KEYFLAG) != 0;
+        const uint32_t tk =
+            ((uint32_t) (e[i] >> VSA_KEYSHIFT) & VSA_KEYMASK) >> ksh;
+        lo += (tk < qk) ? 1u : 0u;
+      }
+    }
+  }
+  // larger buckets: binary search; trip count = that of the largest such
+  // bucket in the wavefront, so the lanes stay converged
+  uint32_t hi = (searching && !small) ? cnt : 0;
   uint32_t maxcnt = hi;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
@@ -511,10 +544,10 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     if (lo < hi)
     {
       const uint32_t mid = (lo + hi) >> 1;
-      const uint64_t e = vsa_ld_entry(ix.esa8 + (uint64_t) dl + mid, nt);
-      flagged = flagged || (e & VSA_KEYFLAG) != 0;
-      const uint32_t tk = ((uint32_t) (e >> VSA_KEYSHIFT) & VSA_KEYMASK) >>
-                          (2 * (VSA_KEYSYMS - limit));
+      const uint64_t em = vsa_ld_entry(ix.esa8 + (uint64_t) dl + mid, nt);
+      flagged = flagged || (em & VSA_KEYFLAG) != 0;
+      const uint32_t tk =
+          ((uint32_t) (em >> VSA_KEYSHIFT) & VSA_KEYMASK) >> ksh;
       if (tk < qk)
       {
         lo = mid + 1;
@@ -525,28 +558,39 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     }
   }
   // neighbours of the insertion point: pred = lo-1, succ = lo, and succ+1
-  // for the size of a tie; three independent loads.  pred/succ/next are
-  // fetched by suffix-array index whether or not they lie in the bucket:
-  // their lcp bytes serve the uniqueness test of the located suffix.
+  // for the size of a tie.  They are taken by suffix-array index whether or
+  // not they lie in the bucket: their lcp bytes serve the uniqueness test of
+  // the located suffix.
   uint64_t epred = 0, esucc = 0, enext = 0;
   bool haspred = false, hassucc = false, hasnext = false;
   if (searching)
   {
-    const uint64_t base = (uint64_t) dl + lo;
     haspred = lo > 0;
     hassucc = lo < cnt;
     hasnext = lo + 1 < cnt;
-    if (base > 0)
+    if (small)
     {
-      epred = vsa_ld_entry(ix.esa8 + base - 1, nt);
-    }
-    if (base <= ix.n)
+      // lo <= cnt <= 4: everything is in e[0..4]
+      epred = lo == 1 ? e[0] : (lo == 2 ? e[1] : (lo == 3 ? e[2] : e[3]));
+      esucc = lo == 0 ? e[0]
+                      : (lo == 1 ? e[1]
+                                 : (lo == 2 ? e[2] : (lo == 3 ? e[3] : e[4])));
+      enext = lo == 0 ? e[1] : (lo == 1 ? e[2] : (lo == 2 ? e[3] : e[4]));
+    } else
     {
-      esucc = vsa_ld_entry(ix.esa8 + base, nt);
-    }
-    if (base + 1 <= ix.n)
-    {
-      enext = vsa_ld_entry(ix.esa8 + base + 1, nt);
+      const uint64_t base = (uint64_t) dl + lo;
+      if (base > 0)
+      {
+        epred = vsa_ld_entry(ix.esa8 + base - 1, nt);
+      }
+      if (base <= ix.n)
+      {
+        esucc = vsa_ld_entry(ix.esa8 + base, nt);
+      }
+      if (base + 1 <= ix.n)
+      {
+        enext = vsa_ld_entry(ix.esa8 + base + 1, nt);
+      }
     }
     flagged = flagged || (haspred && (epred & VSA_KEYFLAG) != 0) ||
               (hassucc && (esucc & VSA_KEYFLAG) != 0);
@@ -559,11 +603,10 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
       state = VSA_LOC_SLOW;
     } else
     {
-      const uint32_t sh = 2 * (VSA_KEYSYMS - limit);
       const uint32_t kp = ((uint32_t) (epred >> VSA_KEYSHIFT) & VSA_KEYMASK)
-                          >> sh,
+                          >> ksh,
                      ks = ((uint32_t) (esucc >> VSA_KEYSHIFT) & VSA_KEYMASK)
-                          >> sh;
+                          >> ksh;
       const uint32_t lp = haspred ? vsa_keylcp(kp, qk, limit) : 0,
                      ls = hassucc ? vsa_keylcp(ks, qk, limit) : 0;
       if (hassucc && ls == limit)

@@ -1590,10 +1590,11 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     return 0;
   }
-  // deep prefix: about one to four suffixes per bucket, never shorter than
-  // the reference's prefixlength, table (8 * 4^D bytes) never above ~8n
+  // deep prefix: about one suffix per bucket, never shorter than the
+  // reference's prefixlength; the table takes 8 * 4^D bytes (at most 32n)
+  // D = ceil(log4(n)), at most 16: about one suffix per bucket
   uint32_t D = 1;
-  while (D < 15 && (1ull << (2 * (D + 1))) <= ix->n)
+  while (D < 16 && (1ull << (2 * D)) < ix->n)
   {
     D++;
   }
@@ -1602,15 +1603,15 @@ int vsa_index_make_esa8(vsa_index *ix)
     D = ix->pl;
   }
   const char *fd = getenv("VSA_DEEP_PREFIX");
-  if (fd != nullptr && atoi(fd) >= (int) ix->pl && atoi(fd) <= 15)
+  if (fd != nullptr && atoi(fd) >= (int) ix->pl && atoi(fd) <= 16)
   {
     D = (uint32_t) atoi(fd);
   }
-  if (D > 15)
+  if (D > 16)
   {
     return 0;
   }
-  static_assert(VSA_TIS_BACKPAD >= 15 + VSA_KEYSYMS + 8, "text pad too small");
+  static_assert(VSA_TIS_BACKPAD >= 16 + VSA_KEYSYMS + 8, "text pad too small");
   ix->D = D;
   const char *tune = getenv("VSA_TUNE");
   ix->tune = tune != nullptr ? (uint32_t) atoi(tune) : 0;

@@ -336,8 +336,9 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_bck_init(uint32_t *__restrict__ left, uint32_t *__restrict__ mid,
            uint64_t numofcodes)
 {
-  const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
-  if (c < numofcodes)
+  // grid-stride: 4^16 codes exceed the 2^32 work-items of one launch
+  for (uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+       c < numofcodes; c += (uint64_t) gridDim.x * VB_BLOCK)
   {
     left[c] = 0xFFFFFFFFu;
     mid[c] = 0xFFFFFFFFu;
@@ -379,21 +380,20 @@ k_bck_finish(const uint32_t *__restrict__ left,
              const uint32_t *__restrict__ mid, uint64_t numofcodes,
              uint32_t *__restrict__ bck)
 {
-  const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
-  if (c >= numofcodes)
+  for (uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+       c < numofcodes; c += (uint64_t) gridDim.x * VB_BLOCK)
   {
-    return;
+    const uint32_t l = left[c];
+    uint32_t m = mid[c];
+    if (m == 0xFFFFFFFFu)
+    {
+      // the last code always holds the end sentinel as a cut suffix, so c+1
+      // exists whenever mid is unset
+      m = left[c + 1];
+    }
+    bck[2 * c] = l;
+    bck[2 * c + 1] = m;
   }
-  const uint32_t l = left[c];
-  uint32_t m = mid[c];
-  if (m == 0xFFFFFFFFu)
-  {
-    // the last code always holds the end sentinel as a cut suffix, so c+1
-    // exists whenever mid is unset
-    m = left[c + 1];
-  }
-  bck[2 * c] = l;
-  bck[2 * c + 1] = m;
 }
 
 // ---- B6: bwt --------------------------------------------------------------
@@ -477,7 +477,10 @@ int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
   {
     return -100;
   }
-  k_bck_init<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
+  const unsigned int codegrid =
+      (unsigned int) std::min<uint64_t>((nc + VB_BLOCK - 1) / VB_BLOCK,
+                                        1u << 22);
+  k_bck_init<<<codegrid, VB_BLOCK, 0, stream>>>(
       left.as<uint32_t>(), mid.as<uint32_t>(), nc);
   VSA_HIP(hipGetLastError());
   k_bck_boundaries<<<gridfor(count), VB_BLOCK, 0, stream>>>(
@@ -494,7 +497,7 @@ int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
   }
   VSA_HIP(rocprim::inclusive_scan(temp.p, tb, rin, rin, (size_t) nc, MinOp(),
                                   stream));
-  k_bck_finish<<<gridfor(nc), VB_BLOCK, 0, stream>>>(
+  k_bck_finish<<<codegrid, VB_BLOCK, 0, stream>>>(
       left.as<uint32_t>(), mid.as<uint32_t>(), nc, out);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(stream));
