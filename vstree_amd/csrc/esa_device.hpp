@@ -41,6 +41,21 @@ __device__ __forceinline__ uint64_t vsa_load8(const uint8_t *p)
   return v;
 }
 
+// sixteen bytes, any alignment: one global_load_dwordx4.  A fully divergent
+// wavefront load costs the address unit about one cycle per lane and
+// instruction, so the search uses few, wide loads.
+struct vsa_u128
+{
+  uint64_t lo, hi;
+};
+
+__device__ __forceinline__ vsa_u128 vsa_load16(const void *p)
+{
+  vsa_u128 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
 // 0x80 in every byte of v that is a special symbol (>= 254)
 __device__ __forceinline__ uint64_t vsa_specialmask(uint64_t v)
 {
@@ -112,11 +127,17 @@ __device__ __forceinline__ int vsa_compare32(const DevIndex<IDX> &ix,
       return 0;
     }
     uint64_t a[4], b[4], m[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
     {
-      a[k] = vsa_load8(query + l + 8 * k);
-      b[k] = vsa_load8(t + l + 8 * k);
+      const vsa_u128 qa = vsa_load16(query + l), qb = vsa_load16(query + l + 16),
+                     ta = vsa_load16(t + l), tb = vsa_load16(t + l + 16);
+      a[0] = qa.lo;
+      a[1] = qa.hi;
+      a[2] = qb.lo;
+      a[3] = qb.hi;
+      b[0] = ta.lo;
+      b[1] = ta.hi;
+      b[2] = tb.lo;
+      b[3] = tb.hi;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -442,8 +463,8 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   if (active)
   {
     // 32 query symbols as four 8-byte words (the buffer is padded)
-    const uint64_t w0 = vsa_load8(query), w1 = vsa_load8(query + 8),
-                   w2 = vsa_load8(query + 16), w3 = vsa_load8(query + 24);
+    const vsa_u128 qlo = vsa_load16(query), qhi = vsa_load16(query + 16);
+    const uint64_t w0 = qlo.lo, w1 = qlo.hi, w2 = qhi.lo, w3 = qhi.hi;
     const uint64_t s0 = vsa_specialmask(w0), s1 = vsa_specialmask(w1),
                    s2 = vsa_specialmask(w2), s3 = vsa_specialmask(w3);
     uint32_t valid = 32; // leading regular symbols inside the query
@@ -502,14 +523,14 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   uint64_t e[5] = {0, 0, 0, 0, 0};
   if (small)
   {
-#pragma unroll
-    for (uint32_t i = 0; i < 5; i++)
-    {
-      if ((uint64_t) dl + i <= ix.n)
-      {
-        e[i] = vsa_ld_entry(ix.esa8 + (uint64_t) dl + i, nt);
-      }
-    }
+    // esa8 has eight entries of slack behind index n
+    const uint64_t *p = ix.esa8 + (uint64_t) dl;
+    const vsa_u128 e01 = vsa_load16(p), e23 = vsa_load16(p + 2);
+    e[0] = e01.lo;
+    e[1] = e01.hi;
+    e[2] = e23.lo;
+    e[3] = e23.hi;
+    e[4] = vsa_ld_entry(p + 4, nt);
   }
   // lower bound on keys: lo = number of bucket entries whose key is smaller
   // than the query's

@@ -1257,6 +1257,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     deepok = ix.esa8 != nullptr && searchlength >= ix.D;
   }
+  tall.start();
   // MUM modes over batches of equal-length queries: anchor pass + work list
   DevBuf wcount, wbase, wlq, wloff, wtemp;
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
@@ -1332,7 +1333,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       std::max<uint64_t>((queries->nq * 2 / nshards) * 5 / 4 + 64, 256);
   uint64_t needed = 0, maxshard = 0;
   double searchms = 0;
-  tall.start();
   for (int attempt = 0; attempt < 2; attempt++)
   {
     if (rawout.alloc(nshards * shardcap * sizeof(vsa_match)) ||
