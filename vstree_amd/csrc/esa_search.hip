@@ -560,12 +560,21 @@ k_mum_anchor(const DevIndex<IDX> ix, const DevQueries qs, uint32_t perquery,
       {
         // 32 symbols per round trip, most recent first
         uint64_t m[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
         {
-          const uint64_t a = vsa_load8(qptr - k - 8 * (i + 1)),
-                         b = vsa_load8(ix.tis + sufstart - k - 8 * (i + 1));
-          m[i] = (a ^ b) | vsa_specialmask(a) | vsa_specialmask(b);
+          // bytes [-32, 0) in front of the current position, two 16-byte
+          // loads per side; word 0 = the most recent eight symbols
+          const vsa_u128 qn = vsa_load16(qptr - k - 16),
+                         qf = vsa_load16(qptr - k - 32),
+                         tn = vsa_load16(ix.tis + sufstart - k - 16),
+                         tf = vsa_load16(ix.tis + sufstart - k - 32);
+          const uint64_t a[4] = {qn.hi, qn.lo, qf.hi, qf.lo},
+                         b[4] = {tn.hi, tn.lo, tf.hi, tf.lo};
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+          {
+            m[i] = (a[i] ^ b[i]) | vsa_specialmask(a[i]) |
+                   vsa_specialmask(b[i]);
+          }
         }
         if ((m[0] | m[1] | m[2] | m[3]) == 0)
         {
