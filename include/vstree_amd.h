@@ -104,6 +104,21 @@ int vsa_index_build(const uint8_t *tis, uint64_t totallength,
                     uint32_t numofchars, uint32_t prefixlength, int device,
                     vsa_index **index);
 
+/*
+  mkvtree on the GPU: reads multiple-FASTA files like
+  `mkvtree -db dbfiles.. [-q queryfiles..] -indexname NAME -dna -pl [n] -allout`
+  (Mkvtree/mkvtree.c:689, input Mkvtree/mkvinput.c:173, DNA symbol map) and
+  writes NAME.{prj,al1,tis,ois,des,sds,ssp,suf,lcp,llv,bck,bwt,sti1[,skp]} byte
+  for byte as the reference does (Mkvtree/mkvprocess.c:99-816); the reference's
+  vmatch reads them.  prefixlength 0 = the reference's recommendation;
+  integersize 64 matches the reference's LP64 build, 32 halves suf/bck/llv.
+  Plain (uncompressed) FASTA only.
+*/
+int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
+                const char *const *queryfiles, uint32_t numofqueryfiles,
+                const char *indexname, uint32_t prefixlength,
+                uint32_t integersize, int withskp, int device);
+
 /* same, for a text that already lives in device memory (bench.py) */
 int vsa_index_build_device(const void *device_tis, uint64_t totallength,
                            uint32_t numofchars, uint32_t prefixlength,

@@ -54,7 +54,13 @@ def index_case(wd, indexname, mkvargs):
     prj = H.read_prj(prefix + ".prj")
     return {"prj": {k: v for k, v in prj.items()
                     if k not in ("dbfile", "queryfile")},
-            "md5": {t: md5file(prefix + "." + t) for t in TABLES}}
+            "md5": {t: md5file(prefix + "." + t) for t in TABLES},
+            "mkvargs": mkvargs, "indexname": indexname,
+            "md5_allfiles": {t: md5file(prefix + "." + t)
+                             for t in ("prj", "al1", "tis", "ois", "des",
+                                       "sds", "ssp", "suf", "lcp", "llv",
+                                       "bck", "bwt", "sti1", "skp")
+                             if os.path.exists(prefix + "." + t)}}
 
 
 def run_case(wd, args):

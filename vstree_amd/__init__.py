@@ -80,6 +80,8 @@ def _load():
         "vsa_index_build": (I, [V, U64, U32, U32, I, PP]),
         "vsa_index_build_device": (I, [V, U64, U32, U32, I, PP]),
         "vsa_index_download": (I, [V, V, V, V, V, V, V]),
+        "vsa_mkvtree": (I, [C.POINTER(C.c_char_p), U32, C.POINTER(C.c_char_p),
+                            U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
         "vsa_queries_from_device": (I, [V, U64, U32, I, PP]),
         "vsa_queries_free": (None, [V]),
@@ -388,6 +390,17 @@ def synth_query_plan(n, nq, m, seed=QUERY_SEED):
     lib.vsa_synth_query_plan(seed, n, nq, m, _ptr(pos), _ptr(sub),
                              _ptr(step))
     return pos, sub, step
+
+
+def mkvtree(dbfiles, indexname, queryfiles=(), prefixlength=0, integersize=64,
+            withskp=True, device=0):
+    """mkvtree -db .. [-q ..] -indexname .. -dna -pl -allout on the GPU."""
+    db = (C.c_char_p * len(dbfiles))(*[os.fsencode(f) for f in dbfiles])
+    qf = (C.c_char_p * max(1, len(queryfiles)))(
+        *[os.fsencode(f) for f in queryfiles])
+    _check(lib.vsa_mkvtree(db, len(dbfiles), qf, len(queryfiles),
+                           os.fsencode(indexname), prefixlength, integersize,
+                           int(withskp), device))
 
 
 def device_count():
