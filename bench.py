@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=1000000,
                     help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=1)
+    # rehearsal of the N > 1 path on a box with ONE GPU: every rank uses
+    # device 0 and the collectives run over gloo on host copies
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     return ap.parse_args()
 
 
@@ -86,17 +89,20 @@ def main():
             log("bench.py: --gpus %d needs torch.distributed.run; running the "
                 "single-process case" % a.gpus)
         a.gpus = world
-    dev = local_rank
-
-    import vstree_amd as V
+    dev = 0 if a.rehearse_on_one_gpu else local_rank
 
     torch = dist = S = None
     if world > 1:
+        # torch first: its wheel bundles a HIP runtime, and the library must
+        # bind to the one runtime of the process (vstree_amd/__init__.py)
         import torch
         import torch.distributed as dist
+    import vstree_amd as V
+    if world > 1:
         from vstree_amd import sharding as S
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if a.rehearse_on_one_gpu else "nccl",
+                                rank=rank, world_size=world)
 
     n, nq, m, L = int(a.genome), int(a.queries), a.qlen, a.minlen
 
@@ -152,20 +158,24 @@ def main():
                            device="cuda")[:r.count * 4]
         r.copy_device(C.c_void_p(mine.data_ptr()), r.count)
         r.close()
+        cdev = "cuda"
+        if a.rehearse_on_one_gpu:
+            mine, cdev = mine.cpu(), "cpu"
 
         # phase 2: the one exchange step -- candidates of all ranks over
         # RCCL, uniqueness filter (vsa_mumuniqueinquery) on rank 0
         def filter_fn(allc):
+            allc = allc.cuda()
             res = V.mumuniqueinquery(C.c_void_p(allc.data_ptr()),
                                      allc.numel() // 4, dev)
             st = res.stats()
             res.close()
             return st.count, st.sumlength
 
-        nmum, sumlen, ncand = S.global_mum_filter(dist, torch, mine, "cuda",
+        nmum, sumlen, ncand = S.global_mum_filter(dist, torch, mine, cdev,
                                                   filter_fn)
         # final reduction of the remaining match counters
-        searches, = S.all_reduce_counters(dist, torch, [s.searches], "cuda")
+        searches, = S.all_reduce_counters(dist, torch, [s.searches], cdev)
         totals = (nmum, sumlen, searches, ncand)
 
     for _ in range(a.warmup):
@@ -178,7 +188,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        e = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if a.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
 

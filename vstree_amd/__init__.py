@@ -15,6 +15,21 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(_HERE, "libvstree_amd.so")
+# same code without a link-time dependency on libamdhip64 (see csrc/Makefile)
+LIBPATH_NORT = os.path.join(_HERE, "libvstree_amd_nort.so")
+
+
+def _loaded_hip_runtime():
+    """path of a libamdhip64 already mapped into this process, if any (e.g.
+    the one a PyTorch wheel bundles under torch/lib)"""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return None
 
 SEPARATOR = 255
 WILDCARD = 254
@@ -63,11 +78,18 @@ PROCESSMATCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
 def _load():
+    global LIBPATH
     if not os.path.exists(LIBPATH):
         raise ImportError(
             "%s is missing: build it with `make -C vstree_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback"
             % LIBPATH)
+    hip = _loaded_hip_runtime()
+    if hip is not None and os.path.exists(LIBPATH_NORT):
+        # one HIP runtime per process: bind to the one that is already here
+        # (import torch BEFORE vstree_amd when both are used)
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        LIBPATH = LIBPATH_NORT
     lib = C.CDLL(LIBPATH)
     V, U64, U32, I = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     PP = C.POINTER(C.c_void_p)
