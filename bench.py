@@ -14,8 +14,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the index is
 replicated, every rank owns 10 M queries of a 10*N M query job (weak
 scaling).  Phase 1 (search) needs no communication; the MUM uniqueness filter
 (kurtz/cleanMUMcand.c of the reference) is one global step: candidates are
-all-gathered over RCCL and filtered on rank 0; one RCCL all-reduce sums the
-match counters.
+range-partitioned by database position over the ranks (RCCL all-to-all), every
+rank filters its range with the carry of the lower ranges; one RCCL all-reduce
+sums the match counters.
 
 Prints ONE JSON line on rank 0.  Extra objects: "roofline" (dominant kernel
 k_query_search, algorithmic bytes from the instrumented CPU restatement) and
@@ -162,18 +163,19 @@ def main():
         if a.rehearse_on_one_gpu:
             mine, cdev = mine.cpu(), "cpu"
 
-        # phase 2: the one exchange step -- candidates of all ranks over
-        # RCCL, uniqueness filter (vsa_mumuniqueinquery) on rank 0
-        def filter_fn(allc):
-            allc = allc.cuda()
-            res = V.mumuniqueinquery(C.c_void_p(allc.data_ptr()),
-                                     allc.numel() // 4, dev)
+        # phase 2: the one exchange step -- candidates are range-partitioned
+        # by dbstart over the ranks (RCCL all-to-all), every rank runs the
+        # uniqueness filter on its range with the carry of the lower ranges
+        def filter_fn(part, carry):
+            part = part.cuda().contiguous()
+            res = V.mumuniqueinquery_range(C.c_void_p(part.data_ptr()),
+                                           part.numel() // 4, carry, dev)
             st = res.stats()
             res.close()
             return st.count, st.sumlength
 
-        nmum, sumlen, ncand = S.global_mum_filter(dist, torch, mine, cdev,
-                                                  filter_fn)
+        nmum, sumlen, ncand = S.partitioned_mum_filter(dist, torch, mine, n,
+                                                       cdev, filter_fn)
         # final reduction of the remaining match counters
         searches, = S.all_reduce_counters(dist, torch, [s.searches], cdev)
         totals = (nmum, sumlen, searches, ncand)

@@ -249,6 +249,18 @@ int vsa_mumuniqueinquery(void *device_candidates, uint64_t ncandidates,
                          int device, vsa_result **result);
 
 /*
+  The same filter on ONE dbstart range of a job whose candidates are
+  partitioned by dbstart over several GPUs: carry_dbright = the largest
+  right end (dbstart + length - 1) among all candidates with a smaller
+  dbstart, i.e. the value the reference's running variable `dbright`
+  (kurtz/cleanMUMcand.c:63,90) has when its loop reaches this range.  Equal
+  dbstarts must not be split between ranges.
+*/
+int vsa_mumuniqueinquery_range(void *device_candidates, uint64_t ncandidates,
+                               int device, uint64_t carry_dbright,
+                               vsa_result **result);
+
+/*
   The same three entry points with the reference's delivery model: every
   match is handed to a callback on the calling thread, in reference order;
   a non-zero return stops the run and is propagated

@@ -73,7 +73,15 @@ static int compare_mumcand(const void *pv, const void *qv)
    whole query set; survivors leave in dbstart order */
 int orc_mumuniqueinquery(orc_match *cand, uint64_t ncand, orc_matches *out)
 {
-  uint64_t i, dbright = 0, currentright;
+  return orc_mumuniqueinquery_carry(cand, ncand, 0, out);
+}
+
+/* the same loop entered with a given value of the running variable dbright:
+   what the reference's loop does from the middle of a sorted list on */
+int orc_mumuniqueinquery_carry(orc_match *cand, uint64_t ncand,
+                               uint64_t carry, orc_matches *out)
+{
+  uint64_t i, dbright = carry, currentright;
   int ignorecurrent, ignoreprevious = 0;
 
   if (ncand == 0)

@@ -124,6 +124,8 @@ int orc_findmaximaluniquematches(const orc_index *idx, uint64_t searchlength,
 
 /* kurtz/cleanMUMcand.c:55-118 on its own (cand is sorted in place) */
 int orc_mumuniqueinquery(orc_match *cand, uint64_t ncand, orc_matches *out);
+int orc_mumuniqueinquery_carry(orc_match *cand, uint64_t ncand,
+                               uint64_t carry, orc_matches *out);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,9 @@ def oracle_lib():
             C.c_char_p]
         lib.orc_mumuniqueinquery.argtypes = [C.c_void_p, C.c_uint64,
                                              C.POINTER(OrcMatches)]
+        lib.orc_mumuniqueinquery_carry.argtypes = [C.c_void_p, C.c_uint64,
+                                                   C.c_uint64,
+                                                   C.POINTER(OrcMatches)]
         lib.orc_recommendedprefixlength.argtypes = [C.c_uint32, C.c_uint64]
         lib.orc_recommendedprefixlength.restype = C.c_uint32
         lib.orc_build_tables.argtypes = [
@@ -270,6 +273,17 @@ def oracle_selfmum(index, searchlength):
     if rc != 0:
         raise OracleError(err.value.decode())
     return res
+
+
+def oracle_mumfilter(cand, carry=0):
+    """kurtz/cleanMUMcand.c:55-118 on a candidate array (copied)"""
+    lib = oracle_lib()
+    out = OrcMatches()
+    lib.orc_matches_init(C.byref(out))
+    c2 = np.ascontiguousarray(cand.copy())
+    lib.orc_mumuniqueinquery_carry(c2.ctypes.data, len(c2), int(carry),
+                                   C.byref(out))
+    return _take(out)
 
 
 def oracle_counters(reset=False):

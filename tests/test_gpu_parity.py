@@ -294,3 +294,31 @@ def test_deep_locate_on_repeats_and_ties(V):
             a = V.findquerymatches(gi, gq, L, **kw).fetch()
             b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
             assert np.array_equal(a, b), (L, kw)
+
+
+def test_mum_filter_in_dbstart_ranges_equals_whole_filter(V):
+    """vsa_mumuniqueinquery_range with the carry of the lower ranges, range by
+    range, gives the list of the one-piece filter (multi-GPU path)"""
+    import ctypes as C
+    idx, q = H.load_case("c1")
+    gi, gq = gpu_index(V, "c1"), gpu_queries(V, q)
+    cand = V.findquerymatches(gi, gq, 20, mum=True, cand=True).fetch()
+    want = V.findquerymatches(gi, gq, 20, mum=True).fetch()
+    assert np.array_equal(want, H.oracle_mumfilter(cand))
+    pieces, carry, world = [], 0, 3
+    dest = (cand["dbstart"] * np.uint64(world)) // np.uint64(idx.n + 1)
+    for r in range(world):
+        part = np.ascontiguousarray(cand[dest == r])
+        dp = V.device_malloc(max(part.nbytes, 16))
+        # upload through a query-independent path: hipMemcpy via from_host
+        import torch
+        t = torch.from_numpy(part.view(np.uint64).astype(np.int64)).cuda()
+        res = V.mumuniqueinquery_range(C.c_void_p(t.data_ptr()), len(part),
+                                       carry)
+        pieces.append(res.fetch())
+        assert np.array_equal(pieces[-1], H.oracle_mumfilter(part, carry))
+        if len(part):
+            carry = max(carry, int((part["dbstart"] + part["length"]).max())
+                        - 1)
+        V.device_free(dp)
+    assert np.array_equal(np.concatenate(pieces), want)

@@ -39,19 +39,27 @@ def _worker(rank, world, port, outdir):
 
     def filter_fn(allc):
         arr = S.tensor_to_matches(allc, H.MATCH_DTYPE)
-        import ctypes as C
-        out = H.OrcMatches()
-        lib = H.oracle_lib()
-        lib.orc_matches_init(C.byref(out))
-        arr = np.ascontiguousarray(arr)
-        lib.orc_mumuniqueinquery(arr.ctypes.data, len(arr), C.byref(out))
-        mums = H._take(out)
+        mums = H.oracle_mumfilter(arr)
         result["mums"] = mums
         return len(mums), int(mums["length"].sum())
 
     local = S.matches_to_tensor(torch, cand)
     nmum, sumlen, ncand = S.global_mum_filter(dist, torch, local, "cpu",
                                               filter_fn)
+
+    # the scalable variant: candidates range-partitioned by dbstart, every
+    # rank filters its range with the carry of the lower ranges
+    def range_filter_fn(part, carry):
+        arr = S.tensor_to_matches(part, H.MATCH_DTYPE)
+        mums = H.oracle_mumfilter(arr, carry)
+        result["mymums"] = mums
+        return len(mums), int(mums["length"].sum())
+
+    pn, ps, pc = S.partitioned_mum_filter(dist, torch, local, idx.n, "cpu",
+                                          range_filter_fn)
+    assert (pn, ps, pc) == (nmum, sumlen, ncand)
+    pparts, _ = S.all_gather_matches(
+        dist, torch, S.matches_to_tensor(torch, result["mymums"]), "cpu")
     totals = S.all_reduce_counters(dist, torch,
                                    [len(compl), int(compl["length"].sum())],
                                    "cpu")
@@ -62,6 +70,7 @@ def _worker(rank, world, port, outdir):
     if rank == 0:
         allcompl = S.tensor_to_matches(torch.cat(parts), H.MATCH_DTYPE)
         np.savez(os.path.join(outdir, "out.npz"), mums=result["mums"],
+                 pmums=S.tensor_to_matches(torch.cat(pparts), H.MATCH_DTYPE),
                  compl=allcompl, nmum=nmum, sumlen=sumlen, ncand=ncand,
                  totals=np.array(totals))
     dist.barrier()
@@ -83,6 +92,8 @@ def test_two_ranks_reproduce_the_single_process_reference(tmp_path):
     want_mum = H.expected("c1", "mum20")
     got_mum = H.matches_as_ref(idx, out["mums"])
     assert np.array_equal(got_mum, want_mum)
+    # range-partitioned filter: rank order = dbstart order, same list
+    assert np.array_equal(H.matches_as_ref(idx, out["pmums"]), want_mum)
     assert int(out["nmum"]) == len(want_mum) == 10323
     assert int(out["sumlen"]) == int(want_mum["length"].sum())
     assert int(out["ncand"]) == len(H.expected("c1", "mumcand20"))

@@ -115,6 +115,7 @@ def _load():
         "vsa_result_free": (None, [V]),
         "vsa_result_copy_device": (I, [V, V, U64]),
         "vsa_mumuniqueinquery": (I, [V, U64, I, PP]),
+        "vsa_mumuniqueinquery_range": (I, [V, U64, I, U64, PP]),
         "vsa_index_make_sti1": (I, [V, V]),
         "vsa_findcompletematches": (I, [V, V, PP]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
@@ -349,6 +350,16 @@ def mumuniqueinquery(device_candidates, ncandidates, device=0):
     h = C.c_void_p()
     _check(lib.vsa_mumuniqueinquery(device_candidates, int(ncandidates),
                                     device, C.byref(h)))
+    return Result(h)
+
+
+def mumuniqueinquery_range(device_candidates, ncandidates, carry_dbright,
+                           device=0):
+    """the filter on one dbstart range (multi-GPU), see the header"""
+    h = C.c_void_p()
+    _check(lib.vsa_mumuniqueinquery_range(device_candidates,
+                                          int(ncandidates), device,
+                                          int(carry_dbright), C.byref(h)))
     return Result(h)
 
 

@@ -1079,10 +1079,20 @@ k_mum_gather(const vsa_match *__restrict__ cand,
   }
 }
 
+// carry = the reference's running `dbright` when it reaches the first of
+// these candidates: 0 for a whole job, the largest right end of all
+// candidates with a smaller dbstart when the list is one dbstart range of a
+// job that is filtered in pieces (multi-GPU).  *maxright (optional) receives
+// the largest right end in this list.
 int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
-                     DevBuf &mums, uint64_t *nmums)
+                     DevBuf &mums, uint64_t *nmums, uint64_t carry = 0,
+                     uint64_t *maxright = nullptr)
 {
   *nmums = 0;
+  if (maxright != nullptr)
+  {
+    *maxright = 0;
+  }
   if (ncand == 0)
   {
     return 0;
@@ -1179,7 +1189,7 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   }
   size_t tb = 0;
   VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
-                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  dbright.as<uint64_t>(), carry,
                                   (size_t) ncand, rocprim::maximum<uint64_t>(),
                                   stream));
   if (temp.alloc(tb))
@@ -1187,9 +1197,20 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
     return -100;
   }
   VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
-                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  dbright.as<uint64_t>(), carry,
                                   (size_t) ncand, rocprim::maximum<uint64_t>(),
                                   stream));
+  if (maxright != nullptr)
+  {
+    // sorted by dbstart, so the running maximum behind the last element
+    uint64_t lastend = 0, lastmax = 0;
+    VSA_HIP(hipMemcpyAsync(&lastend, ends.as<uint64_t>() + ncand - 1, 8,
+                           hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipMemcpyAsync(&lastmax, dbright.as<uint64_t>() + ncand - 1, 8,
+                           hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    *maxright = std::max(lastend, lastmax);
+  }
   k_mum_flags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
       sorted.as<vsa_match>(), ends.as<uint64_t>(), dbright.as<uint64_t>(),
       ncand, keep.as<uint8_t>());
@@ -1770,9 +1791,8 @@ extern "C" int vsa_findquerymatches(const vsa_index *index,
   return 0;
 }
 
-extern "C" int vsa_mumuniqueinquery(void *device_candidates,
-                                    uint64_t ncandidates, int device,
-                                    vsa_result **result)
+static int mumfilter_entry(void *device_candidates, uint64_t ncandidates,
+                           int device, uint64_t carry, vsa_result **result)
 {
   if (result == nullptr || (device_candidates == nullptr && ncandidates > 0))
   {
@@ -1791,7 +1811,7 @@ extern "C" int vsa_mumuniqueinquery(void *device_candidates,
   cand.p = device_candidates; // borrowed, released below
   uint64_t nm = 0;
   tall.start();
-  const int rc = mumuniqueinquery(cand, ncandidates, stream, mums, &nm);
+  const int rc = mumuniqueinquery(cand, ncandidates, stream, mums, &nm, carry);
   tall.stop();
   cand.release();
   if (rc != 0)
@@ -1812,6 +1832,22 @@ extern "C" int vsa_mumuniqueinquery(void *device_candidates,
   }
   *result = res;
   return 0;
+}
+
+extern "C" int vsa_mumuniqueinquery(void *device_candidates,
+                                    uint64_t ncandidates, int device,
+                                    vsa_result **result)
+{
+  return mumfilter_entry(device_candidates, ncandidates, device, 0, result);
+}
+
+extern "C" int vsa_mumuniqueinquery_range(void *device_candidates,
+                                          uint64_t ncandidates, int device,
+                                          uint64_t carry_dbright,
+                                          vsa_result **result)
+{
+  return mumfilter_entry(device_candidates, ncandidates, device,
+                         carry_dbright, result);
 }
 
 extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,

@@ -65,6 +65,61 @@ def global_mum_filter(dist, torch, local_candidates, device, filter_fn):
     return nmum, sumlen, sum(counts)
 
 
+def _exchange_rows(dist, torch, rows, dest, device):
+    """rows [N,4] int64 -> the rows every rank addressed to this rank
+    (dest[i] = receiving rank), concatenated in rank order"""
+    world = dist.get_world_size()
+    order = torch.argsort(dest)
+    rows = rows[order].contiguous()
+    send = torch.bincount(dest, minlength=world).to(torch.int64)
+    recv = torch.zeros_like(send)
+    try:
+        dist.all_to_all_single(recv, send)
+        out = torch.empty((int(recv.sum().item()), MATCH_WORDS),
+                          dtype=torch.int64, device=device)
+        dist.all_to_all_single(out, rows, recv.tolist(), send.tolist())
+        return out
+    except (RuntimeError, NotImplementedError):
+        # backend without all-to-all (gloo in the CPU tests): gather all,
+        # keep what is addressed to this rank
+        parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device)
+        dests, _ = all_gather_matches(
+            dist, torch,
+            torch.sort(dest).values.repeat_interleave(MATCH_WORDS), device)
+        me = dist.get_rank()
+        keep = [p.reshape(-1, MATCH_WORDS)[
+            d.reshape(-1, MATCH_WORDS)[:, 0] == me]
+            for p, d in zip(parts, dests)]
+        return torch.cat(keep) if keep else rows[:0]
+
+
+def partitioned_mum_filter(dist, torch, local_candidates, totallength,
+                           device, filter_fn):
+    """`vmatch -mum` over sharded queries without a single-GPU bottleneck:
+    candidates are range-partitioned by dbstart over the ranks (all-to-all),
+    every rank filters its range with the carry of the ranges below it
+    (vsa_mumuniqueinquery_range), counters are all-reduced.  The MUM list
+    stays distributed; rank order = dbstart order.
+    filter_fn(int64 tensor [n*4], carry) -> (number of MUMs, sum of lengths)
+    Returns (mums, sumlength, candidates) as job-wide totals."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    rows = local_candidates.reshape(-1, MATCH_WORDS)
+    # equal dbstarts always land on the same rank
+    dest = (rows[:, 1] * world) // (int(totallength) + 1)
+    mine = _exchange_rows(dist, torch, rows, dest, device)
+    # carry = largest right end among all candidates of the lower ranges
+    localmax = torch.zeros(1, dtype=torch.int64, device=device)
+    if mine.shape[0] > 0:
+        localmax[0] = (mine[:, 1] + mine[:, 0] - 1).max()
+    allmax = [torch.zeros_like(localmax) for _ in range(world)]
+    dist.all_gather(allmax, localmax)
+    carry = max([0] + [int(m.item()) for m in allmax[:rank]])
+    nmum, sumlen = filter_fn(mine.reshape(-1), carry)
+    nmum, sumlen, ncand = all_reduce_counters(
+        dist, torch, [nmum, sumlen, rows.shape[0]], device)
+    return nmum, sumlen, ncand
+
+
 def matches_to_tensor(torch, matches, device="cpu"):
     """structured numpy match array -> flat int64 tensor"""
     flat = np.ascontiguousarray(matches).view(np.uint64).astype(np.int64)
