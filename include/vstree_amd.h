@@ -302,6 +302,10 @@ int vsa_synth_queries_device(const void *device_genome, uint64_t n,
 /* plain device memory for callers without a HIP runtime of their own */
 int vsa_device_malloc(uint64_t bytes, int device, void **ptr);
 int vsa_device_free(void *ptr, int device);
+int vsa_device_upload(void *device_dst, const void *host_src, uint64_t bytes,
+                      int device);
+int vsa_device_download(void *host_dst, const void *device_src, uint64_t bytes,
+                        int device);
 int vsa_device_count(void);
 int vsa_device_synchronize(int device);
 /* temporaries and freed result lists are recycled inside the library; this

@@ -310,11 +310,8 @@ def test_mum_filter_in_dbstart_ranges_equals_whole_filter(V):
     for r in range(world):
         part = np.ascontiguousarray(cand[dest == r])
         dp = V.device_malloc(max(part.nbytes, 16))
-        # upload through a query-independent path: hipMemcpy via from_host
-        import torch
-        t = torch.from_numpy(part.view(np.uint64).astype(np.int64)).cuda()
-        res = V.mumuniqueinquery_range(C.c_void_p(t.data_ptr()), len(part),
-                                       carry)
+        V.device_upload(dp, part)
+        res = V.mumuniqueinquery_range(dp, len(part), carry)
         pieces.append(res.fetch())
         assert np.array_equal(pieces[-1], H.oracle_mumfilter(part, carry))
         if len(part):

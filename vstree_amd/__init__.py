@@ -131,6 +131,8 @@ def _load():
         "vsa_synth_queries_device": (I, [V, U64, V, V, V, U64, U32, V, I]),
         "vsa_device_malloc": (I, [U64, I, PP]),
         "vsa_device_free": (I, [V, I]),
+        "vsa_device_upload": (I, [V, V, U64, I]),
+        "vsa_device_download": (I, [V, V, U64, I]),
         "vsa_device_count": (I, []),
         "vsa_device_synchronize": (I, [I]),
         "vsa_device_trim": (I, [I]),
@@ -448,6 +450,11 @@ def device_malloc(nbytes, device=0):
     p = C.c_void_p()
     _check(lib.vsa_device_malloc(nbytes, device, C.byref(p)))
     return p
+
+
+def device_upload(dptr, array, device=0):
+    array = np.ascontiguousarray(array)
+    _check(lib.vsa_device_upload(dptr, _ptr(array), array.nbytes, device))
 
 
 def device_free(p, device=0):

@@ -51,6 +51,34 @@ extern "C" int vsa_device_malloc(uint64_t bytes, int device, void **ptr)
   return 0;
 }
 
+extern "C" int vsa_device_upload(void *device_dst, const void *host_src,
+                                 uint64_t bytes, int device)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  if (bytes > 0)
+  {
+    VSA_HIP(hipMemcpy(device_dst, host_src, bytes, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+extern "C" int vsa_device_download(void *host_dst, const void *device_src,
+                                   uint64_t bytes, int device)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  if (bytes > 0)
+  {
+    VSA_HIP(hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 extern "C" int vsa_device_free(void *ptr, int device)
 {
   if (vsa_set_device(device) != 0)
