@@ -129,6 +129,11 @@ int vsa_index_build_device(const void *device_tis, uint64_t totallength,
    not use it, the reference's default algorithm (kurtz/matchsub.c:353) does */
 int vsa_index_make_sti1(const vsa_index *index, uint8_t *sti1);
 
+/* declares the text of a built index as "database, separator at
+   querysepposition, queries" -- what mkvtree -db G -q Q records in the .prj
+   file -- so that vsa_findmaximaluniquematches can run on it */
+int vsa_index_set_queryseparator(vsa_index *index, uint64_t querysepposition);
+
 /* copies the device tables back to host buffers sized by the caller from
    vsa_index_getinfo (entries of suf/bck/llv have device_integersize bits);
    NULL pointers are skipped */

@@ -102,6 +102,7 @@ def _load():
         "vsa_index_build": (I, [V, U64, U32, U32, I, PP]),
         "vsa_index_build_device": (I, [V, U64, U32, U32, I, PP]),
         "vsa_index_download": (I, [V, V, V, V, V, V, V]),
+        "vsa_index_set_queryseparator": (I, [V, U64]),
         "vsa_mkvtree": (I, [C.POINTER(C.c_char_p), U32, C.POINTER(C.c_char_p),
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
@@ -230,6 +231,9 @@ class Index:
                                       _ptr(out["llv"]), _ptr(out["bck"]),
                                       _ptr(out["bwt"])))
         return out
+
+    def set_queryseparator(self, pos):
+        _check(lib.vsa_index_set_queryseparator(self._h, int(pos)))
 
     def make_sti1(self):
         out = np.zeros(self.info().totallength + 1, np.uint8)

@@ -337,6 +337,32 @@ extern "C" int vsa_index_getinfo(const vsa_index *ix, vsa_index_info *info)
   return 0;
 }
 
+extern "C" int vsa_index_set_queryseparator(vsa_index *ix,
+                                            uint64_t querysepposition)
+{
+  if (ix == nullptr || querysepposition >= ix->n)
+  {
+    VSA_ERROR("vsa_index_set_queryseparator: position outside the text");
+    return -1;
+  }
+  uint8_t sym = 0;
+  if (vsa_set_device(ix->device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipMemcpy(&sym, ix->tis_alloc + VSA_TIS_FRONTPAD + querysepposition,
+                    1, hipMemcpyDeviceToHost));
+  if (sym != VSA_SEPARATOR)
+  {
+    VSA_ERROR("position %lu has no separator",
+              (unsigned long) querysepposition);
+    return -2;
+  }
+  ix->querysepposition = querysepposition;
+  ix->hasindexedqueries = 1;
+  return 0;
+}
+
 extern "C" int vsa_index_download(const vsa_index *ix, uint8_t *tis,
                                   void *suf, uint8_t *lcp, void *llv,
                                   void *bck, uint8_t *bwt)
