@@ -13,8 +13,8 @@
 //   K4  k_mum_*             candidates sorted by (dbstart asc, length desc),
 //                           prefix-max scan, flag, compact
 //                           (kurtz/cleanMUMcand.c:55-118)
-//   K3  k_selfmum_scan      streaming scan over lcptab for indexes that hold
-//                           their queries (Vmengine/fmumself.c:10-66)
+//   K3  k_selfmum_peaks     streaming scan over lcptab for indexes that hold
+//       k_selfmum_emit      their queries (Vmengine/fmumself.c:10-66)
 //
 // rocPRIM supplies radix sort / scan / select / reduce only.
 #include <cstring>
@@ -690,106 +690,211 @@ k_mum_flags(const vsa_match *__restrict__ cand,
 // K3: MUMs on an index that contains its queries (Vmengine/fmumself.c:10-66)
 // ---------------------------------------------------------------------------
 
-#define VSA_SCAN_PER_THREAD 16
+// K3a  k_selfmum_peaks: the streaming pass.  A workgroup takes 16 KiB of
+//      lcptab (256 work-items x 4 x one 128-bit load, consecutive lanes on
+//      consecutive 16-byte pieces), every work-item tests its 64 positions on
+//      the lcp bytes alone -- "second >= l, first < second, third < second"
+//      (fmumself.c:36-37) -- and the positions that pass (or that need the
+//      exception table because a byte is 255) leave through ONE cursor
+//      reservation per workgroup.  Nothing else is read: n bytes in, 4 bytes
+//      out per peak.
+// K3b  k_selfmum_emit: one work-item per peak (sorted by position): exact lcp
+//      values, the two suffix starts, the db/query sides, left maximality on
+//      bwt; writes the match and a keep flag, compacted in order afterwards.
+
+#define VSA_PEAK_PIECES 4 // 128-bit loads per work-item
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_selfmum_peaks(const uint8_t *__restrict__ lcp, uint64_t n,
+                uint32_t slmin, uint32_t *__restrict__ outpos,
+                uint64_t shardcap, uint32_t shardmask,
+                unsigned long long *__restrict__ cursors)
+{
+  __shared__ uint16_t tail[VSA_PEAK_PIECES][VSA_BLOCK];
+  __shared__ uint32_t wavesum[VSA_BLOCK / 64];
+  __shared__ uint64_t blockbase;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base =
+      (uint64_t) blockIdx.x * (VSA_BLOCK * VSA_PEAK_PIECES * 16);
+  uint4 v[VSA_PEAK_PIECES];
+
+  // lcp has n+1 entries and at least 32 bytes of zeros behind them; reads
+  // beyond that are clamped away
+#pragma unroll
+  for (int p = 0; p < VSA_PEAK_PIECES; p++)
+  {
+    const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
+    v[p] = (off <= n) ? *reinterpret_cast<const uint4 *>(lcp + off)
+                      : make_uint4(0, 0, 0, 0);
+    tail[p][tid] = (uint16_t) (v[p].w >> 16); // bytes 14, 15 of the piece
+  }
+  __syncthreads();
+  uint32_t hits[VSA_PEAK_PIECES];
+  uint32_t c = 0;
+#pragma unroll
+  for (int p = 0; p < VSA_PEAK_PIECES; p++)
+  {
+    const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
+    // the two bytes in front of this piece
+    uint32_t before;
+    if (tid > 0)
+    {
+      before = tail[p][tid - 1];
+    } else if (p > 0)
+    {
+      before = tail[p - 1][VSA_BLOCK - 1];
+    } else
+    {
+      before = (off >= 2) ? (uint32_t) lcp[off - 2] |
+                                ((uint32_t) lcp[off - 1] << 8)
+                          : 0;
+    }
+    uint8_t b[18];
+    b[0] = (uint8_t) before;
+    b[1] = (uint8_t) (before >> 8);
+    __builtin_memcpy(b + 2, &v[p], 16);
+    uint32_t h = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+      const uint32_t f8 = b[k], s8 = b[k + 1], t8 = b[k + 2];
+      // exact on bytes below 255; a 255 anywhere relevant -> look closer
+      const bool pass = (s8 >= slmin) &&
+                        ((s8 == 255) || (f8 < s8 && t8 < s8));
+      h |= pass ? (1u << k) : 0u;
+    }
+    // positions i = off + k with 2 <= i < n
+    if (off < 2)
+    {
+      h &= ~((1u << (2 - off)) - 1u);
+    }
+    if (off + 16 > n)
+    {
+      h &= (off >= n) ? 0u : ((1u << (n - off)) - 1u);
+    }
+    hits[p] = h;
+    c += (uint32_t) __builtin_popcount(h);
+  }
+  // workgroup-wide exclusive scan of c, one reservation per workgroup
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint32_t incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t) d)
+    {
+      incl += o;
+    }
+  }
+  if (lane == 63)
+  {
+    wavesum[wave] = incl;
+  }
+  __syncthreads();
+  uint32_t wavebase = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < VSA_BLOCK / 64; w++)
+  {
+    wavebase += (w < wave) ? wavesum[w] : 0;
+    total += wavesum[w];
+  }
+  const uint32_t shard = blockIdx.x & shardmask;
+  if (tid == 0)
+  {
+    blockbase = total > 0
+                    ? atomicAdd(cursors + (uint64_t) shard * VSA_CURSOR_STRIDE,
+                                (unsigned long long) total)
+                    : 0;
+  }
+  __syncthreads();
+  uint64_t slot = blockbase + wavebase + incl - c;
+  if (c > 0 && blockbase + total <= shardcap)
+  {
+    uint32_t *dst = outpos + (uint64_t) shard * shardcap;
+#pragma unroll
+    for (int p = 0; p < VSA_PEAK_PIECES; p++)
+    {
+      const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
+      uint32_t h = hits[p];
+      while (h != 0)
+      {
+        const uint32_t k = (uint32_t) __builtin_ctz(h);
+        h &= h - 1;
+        dst[slot++] = (uint32_t) (off + k);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_gather_u32_shards(const uint32_t *__restrict__ in, uint64_t shardcap,
+                    const unsigned long long *__restrict__ cursors,
+                    const uint64_t *__restrict__ offsets,
+                    uint32_t *__restrict__ out)
+{
+  const uint32_t shard = blockIdx.x;
+  const uint64_t count = cursors[(uint64_t) shard * VSA_CURSOR_STRIDE],
+                 src = (uint64_t) shard * shardcap, dst = offsets[shard];
+  for (uint64_t i = threadIdx.x; i < count; i += VSA_BLOCK)
+  {
+    out[dst + i] = in[src + i];
+  }
+}
 
 template <typename IDX>
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_selfmum_scan(const DevIndex<IDX> ix, uint64_t searchlength,
+k_selfmum_emit(const DevIndex<IDX> ix, const uint32_t *__restrict__ peaks,
+               uint64_t npeaks, uint64_t searchlength,
                uint64_t querysepposition, vsa_match *__restrict__ out,
-               uint64_t *__restrict__ outkey, uint64_t capacity,
-               unsigned long long *__restrict__ cursor)
+               uint8_t *__restrict__ keep)
 {
-  // work-item w scans lcp positions i in [16w, 16w+16) intersected with
-  // [2, n); the 16 bytes arrive as one 128-bit load
-  const uint64_t w = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  const uint64_t i0 = w * VSA_SCAN_PER_THREAD;
-  const uint32_t slmin =
-      (uint32_t) (searchlength < 255 ? searchlength : 255);
-  uint32_t c = 0;
-  uint64_t hits = 0; // bit k: position i0+k is a peak that qualifies
-
-  if (i0 < ix.n)
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t >= npeaks)
   {
-    uint8_t b[VSA_SCAN_PER_THREAD + 2];
-    // lcp has n+1 entries and the allocation is padded to a multiple of 16
-    const uint4 v = *reinterpret_cast<const uint4 *>(ix.lcp + i0);
-    __builtin_memcpy(b + 2, &v, 16);
-    b[0] = (i0 >= 2) ? ix.lcp[i0 - 2] : 0;
-    b[1] = (i0 >= 1) ? ix.lcp[i0 - 1] : 0;
-    for (int k = 0; k < VSA_SCAN_PER_THREAD; k++)
-    {
-      const uint64_t i = i0 + k;
-      if (i < 2 || i >= ix.n)
-      {
-        continue;
-      }
-      // bytes first: a peak needs second >= min(searchlength, 255)
-      const uint32_t f8 = b[k], s8 = b[k + 1], t8 = b[k + 2];
-      if (s8 < slmin || f8 > s8 || t8 > s8)
-      {
-        continue;
-      }
-      uint64_t first = f8, second = s8, third = t8;
-      if (s8 == 255)
-      {
-        second = vsa_largelcp(ix, i - 1);
-        first = (f8 == 255) ? vsa_largelcp(ix, i - 2) : f8;
-        third = (t8 == 255) ? vsa_largelcp(ix, i) : t8;
-      }
-      if (second >= searchlength && first < second && third < second)
-      {
-        uint64_t s1 = (uint64_t) ix.suf[i - 2], s2 = (uint64_t) ix.suf[i - 1];
-        if (s1 > s2)
-        {
-          const uint64_t tmp = s1;
-          s1 = s2;
-          s2 = tmp;
-        }
-        if (s1 < querysepposition && s2 > querysepposition)
-        {
-          uint8_t a, bb;
-          if (s1 == 0 || VSA_ISSPECIAL(a = ix.bwt[i - 1]) ||
-              VSA_ISSPECIAL(bb = ix.bwt[i - 2]) || a != bb)
-          {
-            hits |= 1ull << k;
-            c++;
-          }
-        }
-      }
-    }
+    return;
   }
-  const uint64_t mybase = vsa_wave_reserve(cursor, c);
-  if (c > 0 && mybase + c <= capacity)
+  const uint64_t i = peaks[t];
+  uint64_t first = ix.lcp[i - 2], second = ix.lcp[i - 1], third = ix.lcp[i];
+  // SEQUENTIALEVALLCPVALUE (virtualdef.h:121-136) by index instead of in
+  // sequence
+  if (first == 255)
   {
-    uint32_t j = 0;
-    for (int k = 0; k < VSA_SCAN_PER_THREAD; k++)
-    {
-      if (hits & (1ull << k))
-      {
-        const uint64_t i = i0 + k;
-        uint64_t s1 = (uint64_t) ix.suf[i - 2], s2 = (uint64_t) ix.suf[i - 1];
-        if (s1 > s2)
-        {
-          const uint64_t tmp = s1;
-          s1 = s2;
-          s2 = tmp;
-        }
-        uint64_t len = ix.lcp[i - 1];
-        if (len == 255)
-        {
-          len = vsa_largelcp(ix, i - 1);
-        }
-        vsa_match m;
-        m.length = len;
-        m.dbstart = s1;
-        m.queryseq = s2;
-        m.querystart = 0;
-        out[mybase + j] = m;
-        outkey[mybase + j] = i;
-        j++;
-      }
-    }
+    first = vsa_largelcp(ix, i - 2);
   }
+  if (second == 255)
+  {
+    second = vsa_largelcp(ix, i - 1);
+  }
+  if (third == 255)
+  {
+    third = vsa_largelcp(ix, i);
+  }
+  bool ok = second >= searchlength && first < second && third < second;
+  vsa_match m;
+  m.length = second;
+  m.dbstart = m.queryseq = m.querystart = 0;
+  if (ok)
+  {
+    uint64_t s1 = (uint64_t) ix.suf[i - 2], s2 = (uint64_t) ix.suf[i - 1];
+    if (s1 > s2)
+    {
+      const uint64_t tmp = s1;
+      s1 = s2;
+      s2 = tmp;
+    }
+    ok = s1 < querysepposition && s2 > querysepposition;
+    if (ok)
+    {
+      uint8_t a, b;
+      ok = s1 == 0 || VSA_ISSPECIAL(a = ix.bwt[i - 1]) ||
+           VSA_ISSPECIAL(b = ix.bwt[i - 2]) || a != b;
+    }
+    m.dbstart = s1;
+    m.queryseq = s2;
+  }
+  out[t] = m;
+  keep[t] = ok ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1510,60 +1615,116 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   hipStream_t stream = index->stream;
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
-  DevBuf cursor, out, keys;
-  const uint64_t nwork =
-      (index->n + VSA_SCAN_PER_THREAD - 1) / VSA_SCAN_PER_THREAD;
-  uint64_t capacity = 1 << 20, needed = 0;
+  const uint64_t n = index->n;
+  const uint32_t nshards = VSA_CURSOR_SHARDS;
+  const uint64_t perblock = VSA_BLOCK * VSA_PEAK_PIECES * 16;
+  const uint64_t nblocks = (n + 1 + perblock - 1) / perblock;
+  const uint32_t slmin = (uint32_t) (searchlength < 255 ? searchlength : 255);
+  std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
+  DevBuf cursor, doff, rawpos, peaks, sorted, temp, cand, keep, dcount, mums;
+  uint64_t shardcap = std::max<uint64_t>(n / 64 / nshards + 1024, 4096),
+           needed = 0, maxshard = 0;
   double searchms = 0;
 
-  res->stats.searches = index->n;
-  if (cursor.alloc(8))
+  res->stats.searches = n;
+  if (n + 1 >= 0xFFFFFFFFull)
+  {
+    VSA_ERROR("self-index MUM scan: texts beyond 2^32 are not supported");
+    return -3;
+  }
+  if (cursor.alloc(hcur.size() * 8) || doff.alloc(nshards * 8) ||
+      dcount.alloc(8))
   {
     return -100;
   }
   tall.start();
   for (int attempt = 0; attempt < 2; attempt++)
   {
-    if (out.alloc(capacity * sizeof(vsa_match)) || keys.alloc(capacity * 8))
+    if (rawpos.alloc(nshards * shardcap * 4))
     {
       return -100;
     }
-    VSA_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
     tsearch.start();
-    k_selfmum_scan<IDX><<<gridfor(nwork), VSA_BLOCK, 0, stream>>>(
-        ix, searchlength, index->querysepposition, out.as<vsa_match>(),
-        keys.as<uint64_t>(), capacity, cursor.as<unsigned long long>());
+    k_selfmum_peaks<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
+        ix.lcp, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1,
+        cursor.as<unsigned long long>());
     tsearch.stop();
     VSA_HIP(hipGetLastError());
-    VSA_HIP(hipMemcpyAsync(&needed, cursor.p, 8, hipMemcpyDeviceToHost,
-                           stream));
+    VSA_HIP(hipMemcpyAsync(hcur.data(), cursor.p, hcur.size() * 8,
+                           hipMemcpyDeviceToHost, stream));
     VSA_HIP(hipStreamSynchronize(stream));
-    searchms += tsearch.ms();
-    if (needed <= capacity)
+    searchms = tsearch.ms(); // the streaming pass (of the last attempt)
+    needed = maxshard = 0;
+    for (uint32_t sh = 0; sh < nshards; sh++)
+    {
+      const uint64_t cnt = hcur[(uint64_t) sh * VSA_CURSOR_STRIDE];
+      hoff[sh] = needed;
+      needed += cnt;
+      maxshard = std::max(maxshard, cnt);
+    }
+    if (maxshard <= shardcap)
     {
       break;
     }
-    capacity = needed;
+    shardcap = maxshard;
   }
+  if (maxshard > shardcap)
+  {
+    VSA_ERROR("peak buffer overflow");
+    return -5;
+  }
+  uint64_t nm = 0;
   if (needed > 0)
   {
-    DevBuf sk, sm;
-    if (sk.alloc(needed * 8) || sm.alloc(needed * sizeof(vsa_match)))
+    if (peaks.alloc(needed * 4) || sorted.alloc(needed * 4) ||
+        cand.alloc(needed * sizeof(vsa_match)) || keep.alloc(needed) ||
+        mums.alloc(needed * sizeof(vsa_match)))
     {
       return -100;
     }
-    if (sortbykey(keys.as<uint64_t>(), sk.as<uint64_t>(),
-                  out.as<vsa_match>(), sm.as<vsa_match>(), needed,
-                  bitsfor(index->n), stream))
+    VSA_HIP(hipMemcpyAsync(doff.p, hoff.data(), nshards * 8,
+                           hipMemcpyHostToDevice, stream));
+    k_gather_u32_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
+        rawpos.as<uint32_t>(), shardcap, cursor.as<unsigned long long>(),
+        doff.as<uint64_t>(), peaks.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+    // the reference reports in suffix-array order
+    size_t tb = 0;
+    VSA_HIP(rocprim::radix_sort_keys(nullptr, tb, peaks.as<uint32_t>(),
+                                     sorted.as<uint32_t>(), (size_t) needed,
+                                     0u, bitsfor(n), stream));
+    if (temp.alloc(tb))
     {
       return -100;
     }
-    res->count = needed;
-    res->matches = (vsa_match *) sm.release();
+    VSA_HIP(rocprim::radix_sort_keys(temp.p, tb, peaks.as<uint32_t>(),
+                                     sorted.as<uint32_t>(), (size_t) needed,
+                                     0u, bitsfor(n), stream));
+    k_selfmum_emit<IDX><<<gridfor(needed), VSA_BLOCK, 0, stream>>>(
+        ix, sorted.as<uint32_t>(), needed, searchlength,
+        index->querysepposition, cand.as<vsa_match>(), keep.as<uint8_t>());
+    VSA_HIP(hipGetLastError());
+    tb = 0;
+    VSA_HIP(rocprim::select(nullptr, tb, cand.as<vsa_match>(),
+                            keep.as<uint8_t>(), mums.as<vsa_match>(),
+                            dcount.as<uint64_t>(), (size_t) needed, stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::select(temp.p, tb, cand.as<vsa_match>(),
+                            keep.as<uint8_t>(), mums.as<vsa_match>(),
+                            dcount.as<uint64_t>(), (size_t) needed, stream));
+    VSA_HIP(hipMemcpyAsync(&nm, dcount.p, 8, hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    res->count = nm;
+    res->matches = (vsa_match *) mums.release();
   }
   tall.stop();
   VSA_HIP(hipStreamSynchronize(stream));
   res->stats.count = res->count;
+  res->stats.candidates = needed;
   res->stats.search_kernel_ms = searchms;
   res->stats.total_device_ms = tall.ms();
   return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
