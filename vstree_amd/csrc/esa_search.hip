@@ -695,9 +695,10 @@ k_mum_flags(const vsa_match *__restrict__ cand,
 //      consecutive 16-byte pieces), every work-item tests its 64 positions on
 //      the lcp bytes alone -- "second >= l, first < second, third < second"
 //      (fmumself.c:36-37) -- and the positions that pass (or that need the
-//      exception table because a byte is 255) leave through ONE cursor
-//      reservation per workgroup.  Nothing else is read: n bytes in, 4 bytes
-//      out per peak.
+//      exception table because a byte is 255) and whose two suffixes differ
+//      in the symbol to their left (bwt, streamed alongside) leave through
+//      ONE cursor reservation per workgroup.  2n bytes in, 4 bytes out per
+//      surviving peak.
 // K3b  k_selfmum_emit: one work-item per peak (sorted by position): exact lcp
 //      values, the two suffix starts, the db/query sides, left maximality on
 //      bwt; writes the match and a keep flag, compacted in order afterwards.
@@ -705,28 +706,36 @@ k_mum_flags(const vsa_match *__restrict__ cand,
 #define VSA_PEAK_PIECES 4 // 128-bit loads per work-item
 
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_selfmum_peaks(const uint8_t *__restrict__ lcp, uint64_t n,
+k_selfmum_peaks(const uint8_t *__restrict__ lcp,
+                const uint8_t *__restrict__ bwt, uint64_t n,
                 uint32_t slmin, uint32_t *__restrict__ outpos,
                 uint64_t shardcap, uint32_t shardmask,
                 unsigned long long *__restrict__ cursors)
 {
   __shared__ uint16_t tail[VSA_PEAK_PIECES][VSA_BLOCK];
+  __shared__ uint16_t btail[VSA_PEAK_PIECES][VSA_BLOCK];
   __shared__ uint32_t wavesum[VSA_BLOCK / 64];
   __shared__ uint64_t blockbase;
   const uint32_t tid = threadIdx.x;
   const uint64_t base =
       (uint64_t) blockIdx.x * (VSA_BLOCK * VSA_PEAK_PIECES * 16);
-  uint4 v[VSA_PEAK_PIECES];
+  uint4 v[VSA_PEAK_PIECES], u[VSA_PEAK_PIECES];
 
-  // lcp has n+1 entries and at least 32 bytes of zeros behind them; reads
-  // beyond that are clamped away
+  // lcp and bwt have n+1 entries and at least 32 bytes of slack behind them;
+  // reads beyond that are clamped away.  bwt travels with lcp: the left
+  // maximality test (bwt[i-1] != bwt[i-2] or special, fmumself.c:50-52)
+  // removes most peaks right here, so that only real candidates leave the
+  // streaming pass.
 #pragma unroll
   for (int p = 0; p < VSA_PEAK_PIECES; p++)
   {
     const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
     v[p] = (off <= n) ? *reinterpret_cast<const uint4 *>(lcp + off)
                       : make_uint4(0, 0, 0, 0);
+    u[p] = (off <= n) ? *reinterpret_cast<const uint4 *>(bwt + off)
+                      : make_uint4(0, 0, 0, 0);
     tail[p][tid] = (uint16_t) (v[p].w >> 16); // bytes 14, 15 of the piece
+    btail[p][tid] = (uint16_t) (u[p].w >> 16);
   }
   __syncthreads();
   uint32_t hits[VSA_PEAK_PIECES];
@@ -736,32 +745,44 @@ k_selfmum_peaks(const uint8_t *__restrict__ lcp, uint64_t n,
   {
     const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
     // the two bytes in front of this piece
-    uint32_t before;
+    uint32_t before, bbefore;
     if (tid > 0)
     {
       before = tail[p][tid - 1];
+      bbefore = btail[p][tid - 1];
     } else if (p > 0)
     {
       before = tail[p - 1][VSA_BLOCK - 1];
+      bbefore = btail[p - 1][VSA_BLOCK - 1];
     } else
     {
       before = (off >= 2) ? (uint32_t) lcp[off - 2] |
                                 ((uint32_t) lcp[off - 1] << 8)
                           : 0;
+      bbefore = (off >= 2) ? (uint32_t) bwt[off - 2] |
+                                 ((uint32_t) bwt[off - 1] << 8)
+                           : 0;
     }
-    uint8_t b[18];
+    uint8_t b[18], w[18];
     b[0] = (uint8_t) before;
     b[1] = (uint8_t) (before >> 8);
     __builtin_memcpy(b + 2, &v[p], 16);
+    w[0] = (uint8_t) bbefore;
+    w[1] = (uint8_t) (bbefore >> 8);
+    __builtin_memcpy(w + 2, &u[p], 16);
     uint32_t h = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++)
     {
       const uint32_t f8 = b[k], s8 = b[k + 1], t8 = b[k + 2];
       // exact on bytes below 255; a 255 anywhere relevant -> look closer
-      const bool pass = (s8 >= slmin) &&
+      const bool peak = (s8 >= slmin) &&
                         ((s8 == 255) || (f8 < s8 && t8 < s8));
-      h |= pass ? (1u << k) : 0u;
+      // bwt of the two suffixes i-2 and i-1 (the suffix starting at text
+      // position 0 carries 253, which differs from every symbol)
+      const uint8_t ba = w[k + 1], bb = w[k];
+      const bool leftmax = VSA_ISSPECIAL(ba) || VSA_ISSPECIAL(bb) || ba != bb;
+      h |= (peak && leftmax) ? (1u << k) : 0u;
     }
     // positions i = off + k with 2 <= i < n
     if (off < 2)
@@ -1647,7 +1668,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
     tsearch.start();
     k_selfmum_peaks<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
-        ix.lcp, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1,
+        ix.lcp, ix.bwt, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1,
         cursor.as<unsigned long long>());
     tsearch.stop();
     VSA_HIP(hipGetLastError());
