@@ -705,40 +705,6 @@ k_mum_flags(const vsa_match *__restrict__ cand,
 
 #define VSA_PEAK_PIECES 4 // 128-bit loads per work-item
 
-// bytewise unsigned x < y on eight bytes at once; result in bit 7 of a byte
-__device__ __forceinline__ uint64_t vsa_bytes_lt(uint64_t x, uint64_t y)
-{
-  const uint64_t H = 0x8080808080808080ull;
-  // bit 7 of e: low seven bits of x >= low seven bits of y
-  const uint64_t e = (x | H) - (y & ~H);
-  return ((~x & y) | (~(x ^ y) & ~e)) & H;
-}
-
-// bit 7 set in every byte of x that is not zero
-__device__ __forceinline__ uint64_t vsa_bytes_nonzero(uint64_t x)
-{
-  const uint64_t L = 0x7F7F7F7F7F7F7F7Full;
-  return (((x & L) + L) | x) & 0x8080808080808080ull;
-}
-
-// the peak test of fmumself.c:36-37,50-52 on eight positions: f/s/t = first,
-// second, third lcp byte, a/b = bwt of the two suffixes; -> 8-bit mask
-__device__ __forceinline__ uint32_t
-vsa_peakmask8(uint64_t f, uint64_t s, uint64_t t, uint64_t a, uint64_t b,
-              uint32_t slmin)
-{
-  const uint64_t H = 0x8080808080808080ull;
-  const uint64_t minv = 0x0101010101010101ull * slmin;
-  const uint64_t ge = ~vsa_bytes_lt(s, minv) & H;     // second >= l
-  const uint64_t is255 = ~vsa_bytes_nonzero(~s) & H;  // needs the llv table
-  const uint64_t peak = vsa_bytes_lt(f, s) & vsa_bytes_lt(t, s);
-  const uint64_t leftmax = vsa_specialmask(a) | vsa_specialmask(b) |
-                           vsa_bytes_nonzero(a ^ b);
-  const uint64_t m = ge & (is255 | peak) & leftmax;
-  // gather bit 7 of the eight bytes into one byte
-  return (uint32_t) (((m >> 7) * 0x0102040810204080ull) >> 56);
-}
-
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_selfmum_peaks(const uint8_t *__restrict__ lcp,
                 const uint8_t *__restrict__ bwt, uint64_t n,
@@ -797,34 +763,38 @@ k_selfmum_peaks(const uint8_t *__restrict__ lcp,
                                  ((uint32_t) bwt[off - 1] << 8)
                            : 0;
     }
-    // eight positions per 64-bit operation: byte lane k of the words below
-    // holds first / second / third lcp byte and the two bwt bytes of
-    // position off + k (+8 for the upper words)
-    const uint64_t lo = ((uint64_t) v[p].y << 32) | v[p].x,
-                   hi = ((uint64_t) v[p].w << 32) | v[p].z,
-                   blo = ((uint64_t) u[p].y << 32) | u[p].x,
-                   bhi = ((uint64_t) u[p].w << 32) | u[p].z;
-    const uint64_t s0 = (lo << 8) | (before >> 8),
-                   f0 = (lo << 16) | before,
-                   s1 = (hi << 8) | (lo >> 56), f1 = (hi << 16) | (lo >> 48),
-                   a0 = (blo << 8) | (bbefore >> 8),
-                   c0 = (blo << 16) | bbefore,
-                   a1 = (bhi << 8) | (blo >> 56),
-                   c1 = (bhi << 16) | (blo >> 48);
-    const uint32_t h = vsa_peakmask8(f0, s0, lo, a0, c0, slmin) |
-                       (vsa_peakmask8(f1, s1, hi, a1, c1, slmin) << 8);
-    uint32_t hh = h;
+    uint8_t b[18], w[18];
+    b[0] = (uint8_t) before;
+    b[1] = (uint8_t) (before >> 8);
+    __builtin_memcpy(b + 2, &v[p], 16);
+    w[0] = (uint8_t) bbefore;
+    w[1] = (uint8_t) (bbefore >> 8);
+    __builtin_memcpy(w + 2, &u[p], 16);
+    uint32_t h = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+      const uint32_t f8 = b[k], s8 = b[k + 1], t8 = b[k + 2];
+      // exact on bytes below 255; a 255 anywhere relevant -> look closer
+      const bool peak = (s8 >= slmin) &&
+                        ((s8 == 255) || (f8 < s8 && t8 < s8));
+      // bwt of the two suffixes i-2 and i-1 (the suffix starting at text
+      // position 0 carries 253, which differs from every symbol)
+      const uint8_t ba = w[k + 1], bb = w[k];
+      const bool leftmax = VSA_ISSPECIAL(ba) || VSA_ISSPECIAL(bb) || ba != bb;
+      h |= (peak && leftmax) ? (1u << k) : 0u;
+    }
     // positions i = off + k with 2 <= i < n
     if (off < 2)
     {
-      hh &= ~((1u << (2 - off)) - 1u);
+      h &= ~((1u << (2 - off)) - 1u);
     }
     if (off + 16 > n)
     {
-      hh &= (off >= n) ? 0u : ((1u << (n - off)) - 1u);
+      h &= (off >= n) ? 0u : ((1u << (n - off)) - 1u);
     }
-    hits[p] = hh;
-    c += (uint32_t) __builtin_popcount(hh);
+    hits[p] = h;
+    c += (uint32_t) __builtin_popcount(h);
   }
   // workgroup-wide exclusive scan of c, one reservation per workgroup
   const uint32_t lane = tid & 63, wave = tid >> 6;
