@@ -703,148 +703,233 @@ k_mum_flags(const vsa_match *__restrict__ cand,
 //      values, the two suffix starts, the db/query sides, left maximality on
 //      bwt; writes the match and a keep flag, compacted in order afterwards.
 
-#define VSA_PEAK_PIECES 4 // 128-bit loads per work-item
 
+// Four suffix array positions per 32-bit operation.  All helpers deliver
+// their verdict in bit 7 of each byte and leave the other bits undefined.
+#define VSA_B7 0x80808080u
+#define VSA_L7 0x7F7F7F7Fu
+
+// (m & a) | (~m & b), one v_bfi_b32
+__device__ __forceinline__ uint32_t vsa_bfi(uint32_t m, uint32_t a, uint32_t b)
+{
+  return (m & a) | (~m & b);
+}
+
+// bytewise unsigned x < y; ylow = y & VSA_L7.  Where the top bits differ y's
+// top bit decides, elsewhere the carry of ylow + (127 - xlow) into bit 7.
+__device__ __forceinline__ uint32_t vsa_bytes_lt(uint32_t x, uint32_t y,
+                                                 uint32_t ylow)
+{
+  return vsa_bfi(x ^ y, y, ylow + (~x & VSA_L7));
+}
+
+// The peak test of fmumself.c:36-37,50-52 on four suffix array positions:
+// s = lcp bytes of the four centres, f / t = their left / right neighbours,
+// a / b = bwt of the two suffixes of each centre.  Exact on bytes below 255;
+// a centre of 255 always passes and is resolved through llv by k_selfmum_emit.
+// ltmin = vsa_bytes_lt(s, l, ...) comes from the caller, which has it already.
+__device__ __forceinline__ uint32_t
+vsa_peakbits4(uint32_t f, uint32_t s, uint32_t t, uint32_t a, uint32_t b,
+              uint32_t ltmin)
+{
+  const uint32_t slow = s & VSA_L7;
+  const uint32_t is255 = (slow + 0x01010101u) & s;
+  const uint32_t peak = vsa_bytes_lt(f, s, slow) & vsa_bytes_lt(t, s, slow);
+  const uint32_t x = a ^ b;
+  const uint32_t differ = ((x & VSA_L7) + VSA_L7) | x;    // bwt bytes differ
+  const uint32_t special = ((a & VSA_L7) + 0x02020202u) & a; // a >= 254
+  return (is255 | peak) & ~ltmin & (differ | special);
+}
+
+// 16 aligned bytes of a table that is read once (NT: nontemporal hint)
+template <bool NT>
+__device__ __forceinline__ uint4 vsa_stream16(const uint8_t *ptr)
+{
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const v4u *q = reinterpret_cast<const v4u *>(ptr);
+  const v4u r = NT ? __builtin_nontemporal_load(q) : *q;
+  return make_uint4(r.x, r.y, r.z, r.w);
+}
+
+// One wavefront = one tile of (64 * PIECES * 16) suffix array positions at a time;
+// wavefronts walk the tiles grid-stride and never synchronise with each other
+// (no LDS, no barrier).  The loads of the NEXT tile are issued before the
+// current one is examined, so that the arithmetic (about 11 operations per
+// position when every word has an lcp byte >= l, i.e. two near-identical
+// genomes) overlaps the memory stream instead of alternating with it.  A word
+// of four positions runs the full test only if one of its lcp bytes is >= l.
+template <int PIECES>
+struct PeakTile
+{
+  uint4 v[PIECES], u[PIECES];
+  uint32_t lcpbefore, bwtbefore, lcpafter; // halo words, valid in every lane
+};
+
+template <int PIECES, bool NT>
+__device__ __forceinline__ void
+vsa_peak_load(PeakTile<PIECES> &t, const uint8_t *__restrict__ lcp,
+              const uint8_t *__restrict__ bwt, uint64_t n, uint64_t base,
+              uint32_t lane)
+{
+  // lcp and bwt have n+1 entries and at least 32 bytes of slack behind them;
+  // reads beyond that are clamped away
+#pragma unroll
+  for (int p = 0; p < PIECES; p++)
+  {
+    const uint64_t off = base + ((uint64_t) p * 64 + lane) * 16;
+    const bool inside = off <= n;
+    t.v[p] = inside ? vsa_stream16<NT>(lcp + off) : make_uint4(0, 0, 0, 0);
+    t.u[p] = inside ? vsa_stream16<NT>(bwt + off) : make_uint4(0, 0, 0, 0);
+  }
+  t.lcpbefore =
+      (base >= 4) ? *reinterpret_cast<const uint32_t *>(lcp + base - 4) : 0u;
+  t.bwtbefore =
+      (base >= 4) ? *reinterpret_cast<const uint32_t *>(bwt + base - 4) : 0u;
+  t.lcpafter = (base + (64 * PIECES * 16) <= n)
+                   ? *reinterpret_cast<const uint32_t *>(lcp + base +
+                                                         (64 * PIECES * 16))
+                   : 0u;
+}
+
+template <int PIECES, bool NT>
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_selfmum_peaks(const uint8_t *__restrict__ lcp,
                 const uint8_t *__restrict__ bwt, uint64_t n,
                 uint32_t slmin, uint32_t *__restrict__ outpos,
                 uint64_t shardcap, uint32_t shardmask,
-                unsigned long long *__restrict__ cursors)
+                unsigned long long *__restrict__ cursors, uint64_t ntiles)
 {
-  __shared__ uint16_t tail[VSA_PEAK_PIECES][VSA_BLOCK];
-  __shared__ uint16_t btail[VSA_PEAK_PIECES][VSA_BLOCK];
-  __shared__ uint32_t wavesum[VSA_BLOCK / 64];
-  __shared__ uint64_t blockbase;
-  const uint32_t tid = threadIdx.x;
-  const uint64_t base =
-      (uint64_t) blockIdx.x * (VSA_BLOCK * VSA_PEAK_PIECES * 16);
-  uint4 v[VSA_PEAK_PIECES], u[VSA_PEAK_PIECES];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t nwaves = (uint64_t) gridDim.x * (VSA_BLOCK / 64);
+  const uint32_t minv = slmin * 0x01010101u;
+  uint64_t tile = (uint64_t) blockIdx.x * (VSA_BLOCK / 64) + (threadIdx.x >> 6);
+  const uint32_t shard = (uint32_t) tile & shardmask;
+  PeakTile<PIECES> cur;
 
-  // lcp and bwt have n+1 entries and at least 32 bytes of slack behind them;
-  // reads beyond that are clamped away.  bwt travels with lcp: the left
-  // maximality test (bwt[i-1] != bwt[i-2] or special, fmumself.c:50-52)
-  // removes most peaks right here, so that only real candidates leave the
-  // streaming pass.
-#pragma unroll
-  for (int p = 0; p < VSA_PEAK_PIECES; p++)
+  if (tile >= ntiles)
   {
-    const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
-    v[p] = (off <= n) ? *reinterpret_cast<const uint4 *>(lcp + off)
-                      : make_uint4(0, 0, 0, 0);
-    u[p] = (off <= n) ? *reinterpret_cast<const uint4 *>(bwt + off)
-                      : make_uint4(0, 0, 0, 0);
-    tail[p][tid] = (uint16_t) (v[p].w >> 16); // bytes 14, 15 of the piece
-    btail[p][tid] = (uint16_t) (u[p].w >> 16);
+    return;
   }
-  __syncthreads();
-  uint32_t hits[VSA_PEAK_PIECES];
-  uint32_t c = 0;
-#pragma unroll
-  for (int p = 0; p < VSA_PEAK_PIECES; p++)
+  vsa_peak_load<PIECES, NT>(cur, lcp, bwt, n, tile * (64 * PIECES * 16), lane);
+  while (true)
   {
-    const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
-    // the two bytes in front of this piece
-    uint32_t before, bbefore;
-    if (tid > 0)
+    const uint64_t next = tile + nwaves, base = tile * (64 * PIECES * 16);
+    PeakTile<PIECES> nxt;
+    if (next < ntiles)
     {
-      before = tail[p][tid - 1];
-      bbefore = btail[p][tid - 1];
-    } else if (p > 0)
-    {
-      before = tail[p - 1][VSA_BLOCK - 1];
-      bbefore = btail[p - 1][VSA_BLOCK - 1];
-    } else
-    {
-      before = (off >= 2) ? (uint32_t) lcp[off - 2] |
-                                ((uint32_t) lcp[off - 1] << 8)
-                          : 0;
-      bbefore = (off >= 2) ? (uint32_t) bwt[off - 2] |
-                                 ((uint32_t) bwt[off - 1] << 8)
-                           : 0;
+      vsa_peak_load<PIECES, NT>(nxt, lcp, bwt, n, next * (64 * PIECES * 16), lane);
     }
-    uint8_t b[18], w[18];
-    b[0] = (uint8_t) before;
-    b[1] = (uint8_t) (before >> 8);
-    __builtin_memcpy(b + 2, &v[p], 16);
-    w[0] = (uint8_t) bbefore;
-    w[1] = (uint8_t) (bbefore >> 8);
-    __builtin_memcpy(w + 2, &u[p], 16);
-    uint32_t h = 0;
+    uint32_t hits[PIECES];
+    uint32_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++)
+    for (int p = 0; p < PIECES; p++)
     {
-      const uint32_t f8 = b[k], s8 = b[k + 1], t8 = b[k + 2];
-      // exact on bytes below 255; a 255 anywhere relevant -> look closer
-      const bool peak = (s8 >= slmin) &&
-                        ((s8 == 255) || (f8 < s8 && t8 < s8));
-      // bwt of the two suffixes i-2 and i-1 (the suffix starting at text
-      // position 0 carries 253, which differs from every symbol)
-      const uint8_t ba = w[k + 1], bb = w[k];
-      const bool leftmax = VSA_ISSPECIAL(ba) || VSA_ISSPECIAL(bb) || ba != bb;
-      h |= (peak && leftmax) ? (1u << k) : 0u;
-    }
-    // positions i = off + k with 2 <= i < n
-    if (off < 2)
-    {
-      h &= ~((1u << (2 - off)) - 1u);
-    }
-    if (off + 16 > n)
-    {
-      h &= (off >= n) ? 0u : ((1u << (n - off)) - 1u);
-    }
-    hits[p] = h;
-    c += (uint32_t) __builtin_popcount(h);
-  }
-  // workgroup-wide exclusive scan of c, one reservation per workgroup
-  const uint32_t lane = tid & 63, wave = tid >> 6;
-  uint32_t incl = c;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-  {
-    const uint32_t o = __shfl_up(incl, d, 64);
-    if (lane >= (uint32_t) d)
-    {
-      incl += o;
-    }
-  }
-  if (lane == 63)
-  {
-    wavesum[wave] = incl;
-  }
-  __syncthreads();
-  uint32_t wavebase = 0, total = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < VSA_BLOCK / 64; w++)
-  {
-    wavebase += (w < wave) ? wavesum[w] : 0;
-    total += wavesum[w];
-  }
-  const uint32_t shard = blockIdx.x & shardmask;
-  if (tid == 0)
-  {
-    blockbase = total > 0
-                    ? atomicAdd(cursors + (uint64_t) shard * VSA_CURSOR_STRIDE,
-                                (unsigned long long) total)
-                    : 0;
-  }
-  __syncthreads();
-  uint64_t slot = blockbase + wavebase + incl - c;
-  if (c > 0 && blockbase + total <= shardcap)
-  {
-    uint32_t *dst = outpos + (uint64_t) shard * shardcap;
-#pragma unroll
-    for (int p = 0; p < VSA_PEAK_PIECES; p++)
-    {
-      const uint64_t off = base + (uint64_t) p * (VSA_BLOCK * 16) + tid * 16;
-      uint32_t h = hits[p];
-      while (h != 0)
+      const uint64_t off = base + ((uint64_t) p * 64 + lane) * 16;
+      // the words around this piece live in the neighbouring lanes
+      uint32_t wb = __shfl_up(cur.v[p].w, 1, 64),
+               bb = __shfl_up(cur.u[p].w, 1, 64),
+               wa = __shfl_down(cur.v[p].x, 1, 64);
+      if (lane == 0)
       {
-        const uint32_t k = (uint32_t) __builtin_ctz(h);
-        h &= h - 1;
-        dst[slot++] = (uint32_t) (off + k);
+        wb = (p > 0) ? (uint32_t) __builtin_amdgcn_readlane(
+                           (int) cur.v[p > 0 ? p - 1 : 0].w, 63)
+                     : cur.lcpbefore;
+        bb = (p > 0) ? (uint32_t) __builtin_amdgcn_readlane(
+                           (int) cur.u[p > 0 ? p - 1 : 0].w, 63)
+                     : cur.bwtbefore;
+      }
+      if (lane == 63)
+      {
+        wa = (p + 1 < PIECES)
+                 ? (uint32_t) __builtin_amdgcn_readlane(
+                       (int) cur.v[p + 1 < PIECES ? p + 1 : p].x, 0)
+                 : cur.lcpafter;
+      }
+      const uint32_t w[6] = {wb, cur.v[p].x, cur.v[p].y, cur.v[p].z,
+                             cur.v[p].w, wa};
+      const uint32_t b[5] = {bb, cur.u[p].x, cur.u[p].y, cur.u[p].z,
+                             cur.u[p].w};
+      // verdict of centre off + 4k + i lands in bit 8i + 7 - k of h
+      uint32_t h = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        const uint32_t ltmin = vsa_bytes_lt(w[k + 1], minv, minv & VSA_L7);
+        if ((ltmin & VSA_B7) != VSA_B7) // some lcp byte >= l
+        {
+          const uint32_t x =
+              vsa_peakbits4(__builtin_amdgcn_alignbit(w[k + 1], w[k], 24),
+                            w[k + 1],
+                            __builtin_amdgcn_alignbit(w[k + 2], w[k + 1], 8),
+                            b[k + 1],
+                            __builtin_amdgcn_alignbit(b[k + 1], b[k], 24),
+                            ltmin);
+          h |= (x >> k) & (VSA_B7 >> k);
+        }
+      }
+      // centres j with 1 <= j <= n-2 (the reference's i = j+1 runs 2 .. n-1)
+      if (off == 0)
+      {
+        h &= ~0x80u;
+      }
+      if (off + 17 > n)
+      {
+        uint32_t valid = 0;
+        for (uint32_t q = 0; q < 16 && off + q + 2 <= n; q++)
+        {
+          valid |= 1u << (8 * (q & 3u) + 7 - (q >> 2));
+        }
+        h &= valid;
+      }
+      hits[p] = h;
+      c += (uint32_t) __builtin_popcount(h);
+    }
+    // wavefront-wide exclusive scan of c, one reservation per wavefront
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t) d)
+      {
+        incl += o;
       }
     }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total > 0)
+    {
+      unsigned long long wbase = 0;
+      if (lane == 0)
+      {
+        wbase = atomicAdd(cursors + (uint64_t) shard * VSA_CURSOR_STRIDE,
+                          (unsigned long long) total);
+      }
+      wbase = __shfl(wbase, 0, 64);
+      if (c > 0 && wbase + total <= shardcap)
+      {
+        uint32_t *dst = outpos + (uint64_t) shard * shardcap;
+        uint64_t slot = wbase + incl - c;
+#pragma unroll
+        for (int p = 0; p < PIECES; p++)
+        {
+          // position reported = j + 1, as the reference counts it
+          const uint64_t first = base + ((uint64_t) p * 64 + lane) * 16 + 1;
+          uint32_t h = hits[p];
+          while (h != 0)
+          {
+            const uint32_t bit = (uint32_t) __builtin_ctz(h);
+            h &= h - 1;
+            dst[slot++] = (uint32_t) (first + 4 * (7 - (bit & 7u)) + (bit >> 3));
+          }
+        }
+      }
+    }
+    if (next >= ntiles)
+    {
+      break;
+    }
+    cur = nxt;
+    tile = next;
   }
 }
 
@@ -904,18 +989,52 @@ k_selfmum_emit(const DevIndex<IDX> ix, const uint32_t *__restrict__ peaks,
       s1 = s2;
       s2 = tmp;
     }
+    // left maximality (fmumself.c:50-52) was decided exactly by the peak
+    // pass: the suffix at text position 0 carries bwt 253, which differs
+    // from every symbol, so that "start1 == 0" needs no case of its own
     ok = s1 < querysepposition && s2 > querysepposition;
-    if (ok)
-    {
-      uint8_t a, b;
-      ok = s1 == 0 || VSA_ISSPECIAL(a = ix.bwt[i - 1]) ||
-           VSA_ISSPECIAL(b = ix.bwt[i - 2]) || a != b;
-    }
     m.dbstart = s1;
     m.queryseq = s2;
   }
   out[t] = m;
   keep[t] = ok ? 1 : 0;
+}
+
+struct KeepToU32
+{
+  __device__ uint32_t operator()(uint8_t k) const
+  {
+    return k;
+  }
+};
+
+// order-preserving compaction of 32-byte records: slot[] = exclusive scan of
+// keep[] (rocprim::select moves records of this size at a fraction of the
+// memory rate: 3.6 ms for 15.6 M records, this pair of passes 0.2 ms)
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_scatter_kept(const vsa_match *__restrict__ in,
+               const uint8_t *__restrict__ keep,
+               const uint32_t *__restrict__ slot, uint64_t count,
+               vsa_match *__restrict__ out, uint64_t *__restrict__ nkept)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t >= count)
+  {
+    return;
+  }
+  const uint32_t k = keep[t], s = slot[t];
+  if (k != 0)
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + t);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + s);
+    const uint4 lo = src[0], hi = src[1];
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+  if (t == count - 1)
+  {
+    *nkept = (uint64_t) s + k;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -984,6 +1103,35 @@ struct Timer
 inline unsigned int gridfor(uint64_t items)
 {
   return (unsigned int) ((items + VSA_BLOCK - 1) / VSA_BLOCK);
+}
+
+// out[] = the records of in[] with keep != 0, in order; *nkept (device) = count
+int compact_matches(const vsa_match *in, const uint8_t *keep,
+                           uint64_t count, vsa_match *out, uint64_t *nkept,
+                           hipStream_t stream)
+{
+  DevBuf slots, temp;
+  size_t tb = 0;
+  auto keepit = rocprim::make_transform_iterator(keep, KeepToU32());
+
+  if (slots.alloc(count * 4))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, keepit, slots.as<uint32_t>(),
+                                  (uint32_t) 0, (size_t) count,
+                                  rocprim::plus<uint32_t>(), stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
+                                  (uint32_t) 0, (size_t) count,
+                                  rocprim::plus<uint32_t>(), stream));
+  k_scatter_kept<<<gridfor(count), VSA_BLOCK, 0, stream>>>(
+      in, keep, slots.as<uint32_t>(), count, out, nkept);
+  VSA_HIP(hipGetLastError());
+  return 0;
 }
 
 struct MatchLength
@@ -1345,17 +1493,11 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   {
     return -100;
   }
-  tb = 0;
-  VSA_HIP(rocprim::select(nullptr, tb, sorted.as<vsa_match>(),
-                          keep.as<uint8_t>(), mums.as<vsa_match>(),
-                          dcount.as<uint64_t>(), (size_t) ncand, stream));
-  if (temp.alloc(tb))
+  if (compact_matches(sorted.as<vsa_match>(), keep.as<uint8_t>(), ncand,
+                      mums.as<vsa_match>(), dcount.as<uint64_t>(), stream))
   {
     return -100;
   }
-  VSA_HIP(rocprim::select(temp.p, tb, sorted.as<vsa_match>(),
-                          keep.as<uint8_t>(), mums.as<vsa_match>(),
-                          dcount.as<uint64_t>(), (size_t) ncand, stream));
   VSA_HIP(hipMemcpyAsync(nmums, dcount.p, 8, hipMemcpyDeviceToHost, stream));
   VSA_HIP(hipStreamSynchronize(stream));
   return 0;
@@ -1629,6 +1771,25 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
 
 // ---- K3 pipeline ----
 
+// VSA_PEAKVARIANT (experiments): bit 0 = nontemporal loads, bit 1 = tiles of
+// 2 instead of 4 pieces.  Measured at 3 Gbp (dense case, 1024 workgroups):
+// 1.13 ms plain, 1.09 ms nontemporal, 1.40 / 1.35 ms with 2 pieces.
+static int vsa_peakvariant(void)
+{
+  const char *e = getenv("VSA_PEAKVARIANT");
+  return (e != NULL) ? atoi(e) & 3 : 1;
+}
+
+// workgroups of the streaming pass: 4 per CU = all the wavefronts that fit
+// with 100 VGPRs each, every one walking its tiles grid-stride
+// (VSA_PEAKBLOCKS overrides, for experiments)
+static uint64_t vsa_peakblocks(void)
+{
+  const char *e = getenv("VSA_PEAKBLOCKS");
+  const long v = (e != NULL) ? atol(e) : 0;
+  return v > 0 ? (uint64_t) v : 1024;
+}
+
 template <typename IDX>
 int run_selfmum(const vsa_index *index, uint64_t searchlength,
                 vsa_result *res)
@@ -1638,8 +1799,13 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   const DevIndex<IDX> ix = index->view<IDX>();
   const uint64_t n = index->n;
   const uint32_t nshards = VSA_CURSOR_SHARDS;
-  const uint64_t perblock = VSA_BLOCK * VSA_PEAK_PIECES * 16;
-  const uint64_t nblocks = (n + 1 + perblock - 1) / perblock;
+  const int variant = vsa_peakvariant();
+  const uint64_t pieces = (variant & 2) ? 2 : 4, tilesize = 64 * pieces * 16;
+  const uint64_t ntiles = (n + 1 + tilesize - 1) / tilesize,
+                 wavesperblock = VSA_BLOCK / 64;
+  const uint64_t nblocks =
+      std::min<uint64_t>((ntiles + wavesperblock - 1) / wavesperblock,
+                         (uint64_t) vsa_peakblocks());
   const uint32_t slmin = (uint32_t) (searchlength < 255 ? searchlength : 255);
   std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
   DevBuf cursor, doff, rawpos, peaks, sorted, temp, cand, keep, dcount, mums;
@@ -1667,9 +1833,19 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     }
     VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
     tsearch.start();
-    k_selfmum_peaks<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
-        ix.lcp, ix.bwt, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1,
-        cursor.as<unsigned long long>());
+#define VSA_PEAKS(PIECES, NT)                                                 \
+  k_selfmum_peaks<PIECES, NT><<<(unsigned int) nblocks, VSA_BLOCK, 0,         \
+                                stream>>>(                                    \
+      ix.lcp, ix.bwt, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1, \
+      cursor.as<unsigned long long>(), ntiles)
+    switch (variant)
+    {
+      case 1: VSA_PEAKS(4, true); break;
+      case 2: VSA_PEAKS(2, false); break;
+      case 3: VSA_PEAKS(2, true); break;
+      default: VSA_PEAKS(4, false); break;
+    }
+#undef VSA_PEAKS
     tsearch.stop();
     VSA_HIP(hipGetLastError());
     VSA_HIP(hipMemcpyAsync(hcur.data(), cursor.p, hcur.size() * 8,
@@ -1726,17 +1902,11 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
         ix, sorted.as<uint32_t>(), needed, searchlength,
         index->querysepposition, cand.as<vsa_match>(), keep.as<uint8_t>());
     VSA_HIP(hipGetLastError());
-    tb = 0;
-    VSA_HIP(rocprim::select(nullptr, tb, cand.as<vsa_match>(),
-                            keep.as<uint8_t>(), mums.as<vsa_match>(),
-                            dcount.as<uint64_t>(), (size_t) needed, stream));
-    if (temp.alloc(tb))
+    if (compact_matches(cand.as<vsa_match>(), keep.as<uint8_t>(), needed,
+                        mums.as<vsa_match>(), dcount.as<uint64_t>(), stream))
     {
       return -100;
     }
-    VSA_HIP(rocprim::select(temp.p, tb, cand.as<vsa_match>(),
-                            keep.as<uint8_t>(), mums.as<vsa_match>(),
-                            dcount.as<uint64_t>(), (size_t) needed, stream));
     VSA_HIP(hipMemcpyAsync(&nm, dcount.p, 8, hipMemcpyDeviceToHost, stream));
     VSA_HIP(hipStreamSynchronize(stream));
     res->count = nm;
