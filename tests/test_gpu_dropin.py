@@ -133,3 +133,51 @@ def test_selection_function_plugin_still_sees_every_match(tmp_path):
     assert rc0 == 0, err0
     assert sorted(lines) == sorted(lines0)
     assert 0 < len(lines) < M["grumbach"]["runs"]["mem14_sp2"]["lines"]
+
+
+# ---- boundary B2: the reference's dlopen hook for complete matches ---------
+
+PLUGIN_DIR = os.path.join(H.ROOT, "integration", "_build")
+PLUGIN = "cpridxps_amd.so"
+
+needs_plugin = pytest.mark.skipif(
+    not (os.path.exists(os.path.join(PLUGIN_DIR, PLUGIN)) and
+         os.access(H.VMATCH_REF, os.X_OK) and
+         os.access(H.MKVTREE_REF, os.X_OK)),
+    reason="integration/_build/cpridxps_amd.so or oracle/_ref not built")
+
+
+def run_ref_vmatch_with_plugin(args, wd):
+    """the UNMODIFIED reference program; `-complete` gets the plugin's bare
+    name as its argument (parsevm.c:1138-1179), found via LD_LIBRARY_PATH"""
+    args = list(args)
+    k = args.index("-complete")
+    args.insert(k + 1, PLUGIN)
+    e = dict(os.environ)
+    e["LD_LIBRARY_PATH"] = PLUGIN_DIR + os.pathsep + e.get(
+        "LD_LIBRARY_PATH", "")
+    p = subprocess.run([H.VMATCH_REF] + args, cwd=wd, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = [l for l in p.stdout.decode().splitlines()
+             if l and not l.startswith("#")]
+    return p.returncode, lines, p.stderr.decode()
+
+
+@needs_plugin
+@pytest.mark.parametrize("case,key", [
+    ("c1", "complete"), ("c1", "complete_dp"), ("largepat", "complete"),
+    ("micro", "complete"), ("grumbach", "complete_short")])
+def test_reference_vmatch_with_cpridxps_plugin(case, key, tmp_path):
+    """vmatch -complete cpridxps_amd.so -q Q IDX on the unmodified reference
+    binary prints what vmatch -complete -q Q IDX printed: one GPU launch per
+    pass behind the per-query vpluginsearch calls"""
+    wd = str(tmp_path)
+    stage(case, wd)
+    H.run_mkvtree_ref(MKV[case] + ["-dna", "-pl", "-allout"], wd)
+    run = M[case]["runs"][key]
+    rc, lines, err = run_ref_vmatch_with_plugin(run["args"], wd)
+    assert (rc != 0) == (run["rc"] != 0), err
+    if run["rc"] != 0:
+        assert run["stderr"].split(": ", 1)[1] in err
+    md5 = hashlib.md5(("\n".join(lines) + "\n").encode()).hexdigest()
+    assert md5 == run["md5_lines"], (case, key, lines[:3])
