@@ -56,6 +56,12 @@ static void push_match(orc_matches *out, uint64_t length, uint64_t dbstart,
   cnt.emitted++;
 }
 
+void orc_push_match(orc_matches *out, uint64_t length, uint64_t dbstart,
+                    uint64_t queryseq, uint64_t querystart)
+{
+  push_match(out, length, dbstart, queryseq, querystart);
+}
+
 /* kurtz/cleanMUMcand.c:25-45: increasing dbstart, then decreasing length.
    Like the reference's comparator this one never reports equality. */
 static int compare_mumcand(const void *pv, const void *qv)

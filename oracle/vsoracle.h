@@ -127,6 +127,19 @@ int orc_mumuniqueinquery(orc_match *cand, uint64_t ncand, orc_matches *out);
 int orc_mumuniqueinquery_carry(orc_match *cand, uint64_t ncand,
                                uint64_t carry, orc_matches *out);
 
+/* vmatch -complete -e K | -h K -q Q IDX (oracle/vsapprox.c):
+   Vmengine/approxcompl.c:138-199 -> Vmengine/splitesaapm.c:369-558.
+   A match carries the distance in querystart.  percent != 0: threshold =
+   m * distvalue / 100.  -4: configuration not covered by the restatement. */
+int orc_findapproxcompletematches(const orc_index *idx, const uint8_t *qbuf,
+                                  const uint64_t *qstart,
+                                  const uint64_t *qlen, uint64_t nq,
+                                  int doedist, uint64_t distvalue,
+                                  int percent, orc_matches *out, char *err);
+uint64_t orc_getoptsplit(int doedist, uint64_t spliterrorbound,
+                         uint64_t numofchars, uint64_t textlen,
+                         uint64_t patternlength, uint64_t threshold);
+
 #ifdef __cplusplus
 }
 #endif

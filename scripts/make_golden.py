@@ -74,13 +74,14 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     manifest, arrays = {}, {}
 
-    def record(case, key, args, wd, both=False):
+    def record(case, key, args, wd, both=False, approx=False):
         rc, lines, err = run_case(wd, args)
         entry = {"args": args, "rc": rc, "lines": len(lines),
                  "md5_lines": hashlib.md5(
                      ("\n".join(lines) + "\n").encode()).hexdigest()}
         if not both:   # lists with P lines are pinned by their md5 only
-            arrays["%s__%s" % (case, key)] = H.parse_vmatch_lines(lines)
+            arrays["%s__%s" % (case, key)] = H.parse_vmatch_lines(
+                lines, approx=approx)
         else:
             entry["strands"] = "both"
         if rc != 0:
@@ -222,6 +223,68 @@ def main():
                                  "genome.fna"], wd, both=True)
     record(case, "mum20_dp", ["-mum", "-l", "20", "-d", "-p", "-q",
                               "queries.fna", "genome.fna"], wd, both=True)
+    # approximate complete matches (BASELINE.json configs[4] semantics):
+    # edit distance and Hamming distance, threshold 2
+    record(case, "approx_e2", ["-complete", "-e", "2", "-q", "queries.fna",
+                               "genome.fna"], wd, approx=True)
+    record(case, "approx_h2", ["-complete", "-h", "2", "-q", "queries.fna",
+                               "genome.fna"], wd, approx=True)
+    shutil.rmtree(wd)
+
+    # ---- 6. C5 in small: 150 bp (and some 100 bp) reads with up to 3 edit
+    # operations against a 3-sequence text with wildcards and planted repeats
+    wd = tempfile.mkdtemp()
+    case = "c5"
+    rng = np.random.default_rng(20240605)
+    seqs = []
+    for s in range(3):
+        L = 70000
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        unit = rng.integers(0, 4, 400).astype(np.uint8)
+        for r in range(8):          # diverged copies of one unit
+            p = int(rng.integers(0, L - 400))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 6))):
+                u[int(rng.integers(0, 400))] = rng.integers(0, 4)
+            t[p:p + 400] = u
+        t[rng.random(L) < 0.0005] = H.WILDCARD
+        seqs.append(t)
+    qs = []
+    for i in range(2000):
+        s = seqs[int(rng.integers(0, 3))]
+        m = 150 if i % 4 else 100
+        p = int(rng.integers(0, len(s) - m))
+        q = s[p:p + m].copy()
+        q[q == H.WILDCARD] = rng.integers(0, 4)
+        for e in range(int(rng.integers(0, 4))):
+            kind, x = int(rng.integers(0, 3)), int(rng.integers(0, len(q)))
+            if kind == 0:
+                q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4
+            elif kind == 1:
+                q = np.delete(q, x)
+            else:
+                q = np.insert(q, x, rng.integers(0, 4))
+        if i % 97 == 0:
+            q[int(rng.integers(0, len(q)))] = H.WILDCARD
+        qs.append(q.astype(np.uint8))
+    H.write_fasta(wd + "/db.fna", [("s%d" % i, t) for i, t in enumerate(seqs)])
+    H.write_fasta(wd + "/reads.fna", [("r%d" % i, q) for i, q in
+                                      enumerate(qs)], width=1000)
+    gzcopy(wd + "/db.fna", GOLD + "/c5_db.fna.gz")
+    gzcopy(wd + "/reads.fna", GOLD + "/c5_reads.fna.gz")
+    manifest[case] = {"db": ["c5_db.fna.gz"], "query": "c5_reads.fna.gz",
+                      "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "db.fna", ["-db", "db.fna", "-dna", "-pl", "-allout"])
+    for k in (1, 2, 3):
+        record(case, "approx_e%d" % k, ["-complete", "-e", str(k), "-q",
+                                        "reads.fna", "db.fna"], wd,
+               approx=True)
+    record(case, "approx_h2", ["-complete", "-h", "2", "-q", "reads.fna",
+                               "db.fna"], wd, approx=True)
+    record(case, "approx_e2p", ["-complete", "-e", "2p", "-q", "reads.fna",
+                                "db.fna"], wd, approx=True)
+    record(case, "complete", ["-complete", "-q", "reads.fna", "db.fna"], wd)
     shutil.rmtree(wd)
 
     np.savez_compressed(GOLD + "/expected.npz", **arrays)

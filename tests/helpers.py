@@ -56,12 +56,12 @@ def build_oracle():
     """Compile oracle/vsoracle.c if the .so is missing or stale."""
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f)
-            for f in ("vsoracle.c", "vsindex.c", "vsoracle_body.inc",
-                      "vsoracle.h")]
+            for f in ("vsoracle.c", "vsindex.c", "vsapprox.c",
+                      "vsoracle_body.inc", "vsoracle.h")]
     if (not os.path.exists(so) or
             os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", srcs[0],
-                               srcs[1], "-lm", "-o", so])
+                               srcs[1], srcs[2], "-lm", "-o", so])
     return so
 
 
@@ -87,6 +87,10 @@ def oracle_lib():
         lib.orc_findmaximaluniquematches.argtypes = [
             C.POINTER(OrcIndex), C.c_uint64, C.POINTER(OrcMatches),
             C.c_char_p]
+        lib.orc_findapproxcompletematches.argtypes = common + [
+            C.c_int, C.c_uint64, C.c_int, C.POINTER(OrcMatches), C.c_char_p]
+        lib.orc_getoptsplit.argtypes = [C.c_int] + [C.c_uint64] * 5
+        lib.orc_getoptsplit.restype = C.c_uint64
         lib.orc_mumuniqueinquery.argtypes = [C.c_void_p, C.c_uint64,
                                              C.POINTER(OrcMatches)]
         lib.orc_mumuniqueinquery_carry.argtypes = [C.c_void_p, C.c_uint64,
@@ -247,6 +251,29 @@ def oracle_complete(index, queries, online=False):
     return res
 
 
+class OracleNotCovered(OracleError):
+    pass
+
+
+def oracle_approx(index, queries, doedist, distvalue, percent=False):
+    """vmatch -complete -e K | -h K: matches carry the distance in
+    querystart"""
+    lib = oracle_lib()
+    out, err = OrcMatches(), C.create_string_buffer(512)
+    lib.orc_matches_init(C.byref(out))
+    oi = index.orc()
+    rc = lib.orc_findapproxcompletematches(
+        C.byref(oi), *_qargs(queries), int(doedist), int(distvalue),
+        int(percent), C.byref(out), err)
+    res = _take(out)
+    if rc != 0:
+        e = (OracleNotCovered if rc == -4 else OracleError)(
+            err.value.decode())
+        e.partial = res
+        raise e
+    return res
+
+
 def oracle_querymatches(index, queries, searchlength, mum=False, cand=False,
                         speedup=0):
     lib = oracle_lib()
@@ -341,7 +368,8 @@ def fasta_queries(path, symmap=None):
 
 def write_fasta(path, records, width=60):
     """records: list of (description, uint8 code array or bytes of letters)."""
-    letters = np.frombuffer(b"acgt", np.uint8)
+    letters = np.full(256, ord("n"), np.uint8)   # wildcard code 254 -> n
+    letters[:4] = np.frombuffer(b"acgt", np.uint8)
     with open(path, "wb") as f:
         for desc, seq in records:
             if not isinstance(seq, (bytes, bytearray)):
@@ -459,15 +487,21 @@ def run_vmatch_ref(args, cwd, env=None):
     return p.returncode, lines, p.stderr.decode()
 
 
-def parse_vmatch_lines(lines):
+def parse_vmatch_lines(lines, approx=False):
     """default vmatch columns (Vmatch/echomatch.c:878-1020):
     len1 seq1 rel1 D|P len2 seq2 rel2 dist evalue score identity
-    -> structured array (length, dbseq, dbrel, queryseq, querystart)"""
+    -> structured array (length, dbseq, dbrel, queryseq, querystart);
+    approx: -complete -e/-h output, querystart = |dist| (rel2 is 0)"""
     dt = np.dtype([("length", "<u8"), ("dbseq", "<u8"), ("dbrel", "<u8"),
                    ("queryseq", "<u8"), ("querystart", "<u8")])
     out = np.zeros(len(lines), dt)
     for i, l in enumerate(lines):
         f = l.split()
+        if approx:
+            assert int(f[6]) == 0
+            out[i] = (int(f[0]), int(f[1]), int(f[2]), int(f[5]),
+                      abs(int(f[7])))
+            continue
         out[i] = (int(f[0]), int(f[1]), int(f[2]), int(f[5]), int(f[6]))
         assert int(f[4]) == int(f[0]) and int(f[7]) == 0
     return out

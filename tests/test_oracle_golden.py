@@ -14,6 +14,13 @@ M = H.manifest()
 
 def run_oracle(case, key):
     idx, q = H.load_case(case)
+    if key.startswith("approx_"):
+        # approx_e2, approx_h2, approx_e2p: vmatch -complete -e 2 | -h 2 |
+        # -e 2p; the distance travels in the querystart field
+        spec = key[len("approx_"):]
+        m = H.oracle_approx(idx, q, spec[0] == "e", int(spec[1:].rstrip("p")),
+                            percent=spec.endswith("p"))
+        return H.matches_as_ref(idx, m), None
     if key.startswith("complete"):
         try:
             m = H.oracle_complete(idx, q)
