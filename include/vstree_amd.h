@@ -220,6 +220,39 @@ int vsa_findcompletematches(const vsa_index *index,
                             const vsa_queries *queries, vsa_result **result);
 
 /*
+  findcompletematches for approximate matching on the index, vmatch
+  -complete -e K | -h K -q Q IDX: decidefcm -> findedistcompletematchesindex
+  / findhammingcompletematchesindex (Vmengine/fcomplete.c:140-261) ->
+  findapproxcompletematchesindex (Vmengine/approxcompl.c:138-199) ->
+  splitesaapm (Vmengine/splitesaapm.c:458-558).
+    doedist   1: edit distance (-e), 0: Hamming distance (-h)
+    distvalue K;  percent != 0: the threshold is m*K/100 (-e Kp, -h Kp,
+              Vmengine/initcompl.c:52-56)
+  A match is (length, dbstart, queryseq, distance): length = Match.length1
+  (for -e the best-distance, then longest prefix behind dbstart,
+  Vmengine/longestmatch.c; for -h the query length), the distance travels in
+  the querystart field (the number of mismatches for -h, where the reference
+  stores its negative in Match.distance, approxcompl.c:78).  Order: query
+  order; within a query the merged candidate regions in ascending order,
+  within a region DESCENDING dbstart, exactly as the reference's right-to-left
+  verification reports them.
+  Errors: a threshold >= query length is the reference's
+  "threshold=%lu>=%lu=patternlen not allowed" (splitesaapm.c:496-501): the
+  matches of the queries before it are delivered, the return code is -2.
+  VSA_NOT_COVERED (-4), no result: the configuration is one this engine does
+  not implement (a piece threshold > 0 or a single piece, i.e. short patterns
+  with many errors; pieces shorter than prefixlength; alphabets beyond 4
+  symbols; m > 256; Hamming distance with special symbols in a query; a batch
+  mixing thresholds 0 and > 0) -- the caller keeps using its CPU function for
+  such batches (integration/vmengine_shim.c does).
+*/
+#define VSA_NOT_COVERED (-4)
+int vsa_findapproxcompletematches(const vsa_index *index,
+                                  const vsa_queries *queries, int doedist,
+                                  uint64_t distvalue, int percent,
+                                  vsa_result **result);
+
+/*
   findquerymatches (Vmengine/fquery.c:1009-1058) for exact matches:
     domaximaluniquematch = 0                      vmatch -l L        (MEM)
     domaximaluniquematch = 1, ...candidates = 1   vmatch -mum cand -l L
@@ -276,6 +309,11 @@ typedef int (*vsa_processmatch)(void *info, const vsa_match *match);
 int vsa_findcompletematches_cb(const vsa_index *index,
                                const vsa_queries *queries,
                                vsa_processmatch processmatch, void *info);
+int vsa_findapproxcompletematches_cb(const vsa_index *index,
+                                     const vsa_queries *queries, int doedist,
+                                     uint64_t distvalue, int percent,
+                                     vsa_processmatch processmatch,
+                                     void *info);
 int vsa_findquerymatches_cb(const vsa_index *index,
                             const vsa_queries *queries,
                             int domaximaluniquematch,

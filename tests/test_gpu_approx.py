@@ -1,0 +1,149 @@
+"""Approximate complete matches (vmatch -complete -e K | -h K, BASELINE.json
+configs[4]) on the GPU against the golden output of the real reference and
+against the CPU oracle: bit-exact including the reference's order (merged
+regions ascending, start positions descending inside a region).  The distance
+of a match travels in the querystart field."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_parity import gpu_index, gpu_queries
+
+pytestmark = pytest.mark.gpu
+M = H.manifest()
+
+APPROX = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
+          if k.startswith("approx_")]
+
+
+def spec(key):
+    s = key[len("approx_"):]
+    return s[0] == "e", int(s[1:].rstrip("p")), s.endswith("p")
+
+
+def without_special_queries(q):
+    keep = np.array([not (q.symbols[int(s):int(s + l)] >= 254).any()
+                     for s, l in zip(q.start, q.length)])
+    return keep, H.Queries(q.symbols, q.start[keep], q.length[keep])
+
+
+@pytest.mark.parametrize("case,key", APPROX)
+def test_gpu_reproduces_reference_approximate_matches(V, case, key):
+    idx, q = H.load_case(case)
+    doedist, k, pct = spec(key)
+    gi = gpu_index(V, case)
+    want = H.expected(case, key)
+    if not doedist and (q.symbols >= 254).any() and any(
+            (q.symbols[int(s):int(s + l)] >= 254).any()
+            for s, l in zip(q.start, q.length)):
+        # raw byte comparison in the reference (wildcards match each other):
+        # the engine declines the batch ...
+        with pytest.raises(V.VsaError) as ei:
+            V.findapproxcompletematches(gi, gpu_queries(V, q), False, k, pct)
+        assert ei.value.code == V.NOT_COVERED
+        # ... and answers the queries without special symbols
+        keep, q = without_special_queries(q)
+        newnum = np.cumsum(keep) - 1
+        want = want[keep[want["queryseq"].astype(np.int64)]]
+        want["queryseq"] = newnum[want["queryseq"].astype(np.int64)]
+    got = V.findapproxcompletematches(gi, gpu_queries(V, q), doedist, k,
+                                      pct).fetch()
+    got = H.matches_as_ref(idx, got)
+    assert len(got) == len(want)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("doedist", [True, False])
+@pytest.mark.parametrize("m,k", [(100, 2), (150, 2), (64, 1), (33, 1),
+                                 (200, 5), (250, 3), (120, 4)])
+def test_gpu_equals_oracle_on_repeats_and_separators(V, doedist, m, k):
+    """texts with diverged repeats (many overlapping regions), several
+    sequences (separators inside regions) and wildcards; reads with up to
+    k + 1 edit operations"""
+    rng = np.random.default_rng(1000 * m + 10 * k + int(doedist))
+    seqs = []
+    for s in range(3):
+        L = 20000
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        unit = rng.integers(0, 4, m + 40).astype(np.uint8)
+        for r in range(6):
+            p = int(rng.integers(0, L - len(unit)))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 4))):
+                u[int(rng.integers(0, len(u)))] = rng.integers(0, 4)
+            t[p:p + len(u)] = u
+        t[rng.random(L) < 0.001] = H.WILDCARD
+        seqs.append(t)
+    tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
+                          for s in seqs])[:-1].astype(np.uint8)
+    qs = []
+    for i in range(300):
+        s = seqs[int(rng.integers(0, 3))]
+        p = int(rng.integers(0, len(s) - m))
+        q = s[p:p + m].copy()
+        q[q == H.WILDCARD] = rng.integers(0, 4)
+        for e in range(int(rng.integers(0, k + 2))):
+            kind, x = int(rng.integers(0, 3)), int(rng.integers(0, len(q)))
+            if kind == 0 or not doedist:
+                q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4
+            elif kind == 1:
+                q = np.delete(q, x)
+            else:
+                q = np.insert(q, x, rng.integers(0, 4))
+        if doedist and i % 50 == 0:
+            q[int(rng.integers(0, len(q)))] = H.WILDCARD
+        qs.append(q.astype(np.uint8))
+    q = H.Queries.from_list(qs)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    try:
+        want = H.oracle_approx(host, q, doedist, k)
+    except H.OracleNotCovered:
+        with pytest.raises(V.VsaError) as ei:
+            V.findapproxcompletematches(gi, gpu_queries(V, q), doedist, k)
+        assert ei.value.code == V.NOT_COVERED
+        return
+    got = V.findapproxcompletematches(gi, gpu_queries(V, q), doedist,
+                                      k).fetch()
+    assert len(got) == len(want) and len(want) > 100
+    assert np.array_equal(got, want)
+
+
+def test_threshold_not_below_pattern_length_is_the_reference_error(V):
+    idx, q = H.load_case("c5")
+    gi = gpu_index(V, "c5")
+    short = H.Queries.from_list([q.symbols[:150], q.symbols[200:203],
+                                 q.symbols[400:550]])
+    with pytest.raises(V.VsaError) as ei:
+        V.findapproxcompletematches(gi, gpu_queries(V, short), True, 3)
+    assert "threshold=3>=3=patternlen not allowed" in str(ei.value)
+    first = H.Queries.from_list([q.symbols[:150]])
+    assert np.array_equal(ei.value.partial.fetch(),
+                          H.oracle_approx(idx, first, True, 3))
+
+
+def test_uncovered_configurations_are_declined_not_guessed(V):
+    idx, q = H.load_case("c5")
+    gi = gpu_index(V, "c5")
+    # 20 symbols with 3 errors: pieces would need a threshold of their own
+    tiny = H.Queries.from_list([q.symbols[:20], q.symbols[160:180]])
+    with pytest.raises(V.VsaError) as ei:
+        V.findapproxcompletematches(gi, gpu_queries(V, tiny), True, 3)
+    assert ei.value.code == V.NOT_COVERED and ei.value.partial is None
+
+
+def test_threshold_zero_is_the_exact_search(V):
+    idx, q = H.load_case("c5")
+    gi = gpu_index(V, "c5")
+    got = V.findapproxcompletematches(gi, gpu_queries(V, q), True, 0).fetch()
+    assert np.array_equal(got, H.oracle_complete(idx, q))
+
+
+def test_callback_variant_replays_in_order(V):
+    idx, q = H.load_case("c5")
+    gi = gpu_index(V, "c5")
+    want = V.findapproxcompletematches(gi, gpu_queries(V, q), True, 2).fetch()
+    rc, got = V.findapproxcompletematches_cb(gi, gpu_queries(V, q), True, 2)
+    assert rc == 0 and np.array_equal(np.array(got, dtype=want.dtype), want)

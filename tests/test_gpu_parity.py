@@ -52,7 +52,8 @@ def run_gpu(V, case, key, bits=64):
 # one query offset -- so only the _sp0 MEM lists are compared in order, the
 # other MEM lists as sets; complete / MUM / candidate lists always in order
 CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
-         if not k.endswith("_short") and "strands" not in M[c]["runs"][k]]
+         if not k.endswith("_short") and "strands" not in M[c]["runs"][k]
+         and not k.startswith("approx_")]   # those: tests/test_gpu_approx.py
 
 
 @pytest.mark.parametrize("case,key", CASES)

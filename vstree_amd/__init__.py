@@ -119,6 +119,9 @@ def _load():
         "vsa_mumuniqueinquery_range": (I, [V, U64, I, U64, PP]),
         "vsa_index_make_sti1": (I, [V, V]),
         "vsa_findcompletematches": (I, [V, V, PP]),
+        "vsa_findapproxcompletematches": (I, [V, V, I, U64, I, PP]),
+        "vsa_findapproxcompletematches_cb": (I, [V, V, I, U64, I,
+                                                 PROCESSMATCH, V]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
@@ -334,6 +337,26 @@ def findcompletematches(index, queries):
     return res
 
 
+NOT_COVERED = -4
+
+
+def findapproxcompletematches(index, queries, doedist, distvalue,
+                              percent=False):
+    """vmatch -complete -e K | -h K -q (Vmengine/approxcompl.c:138); the
+    distance of a match travels in its querystart field.  VsaError.code ==
+    NOT_COVERED: a configuration the engine leaves to the CPU reference."""
+    h = C.c_void_p()
+    rc = lib.vsa_findapproxcompletematches(index._h, queries._h,
+                                           int(doedist), int(distvalue),
+                                           int(percent), C.byref(h))
+    res = Result(h) if h else None
+    if rc != 0:
+        e = VsaError(rc, messagespace())
+        e.partial = res
+        raise e
+    return res
+
+
 def findquerymatches(index, queries, searchlength, mum=False, cand=False):
     """vmatch [-mum [cand]] -l L -q (Vmengine/fquery.c:1009)."""
     h = C.c_void_p()
@@ -384,6 +407,15 @@ def _collector(stop_after=None):
 def findcompletematches_cb(index, queries, stop_after=None):
     got, cb = _collector(stop_after)
     rc = lib.vsa_findcompletematches_cb(index._h, queries._h, cb, None)
+    return rc, got
+
+
+def findapproxcompletematches_cb(index, queries, doedist, distvalue,
+                                 percent=False, stop_after=None):
+    got, cb = _collector(stop_after)
+    rc = lib.vsa_findapproxcompletematches_cb(
+        index._h, queries._h, int(doedist), int(distvalue), int(percent), cb,
+        None)
     return rc, got
 
 

@@ -63,6 +63,19 @@ int vsa_findcompletematches_cb(const vsa_index *index,
   return replay(result, rc, processmatch, info);
 }
 
+int vsa_findapproxcompletematches_cb(const vsa_index *index,
+                                     const vsa_queries *queries, int doedist,
+                                     uint64_t distvalue, int percent,
+                                     vsa_processmatch processmatch,
+                                     void *info)
+{
+  vsa_result *result = NULL;
+  int rc = vsa_findapproxcompletematches(index, queries, doedist, distvalue,
+                                         percent, &result);
+
+  return replay(result, rc, processmatch, info);
+}
+
 int vsa_findquerymatches_cb(const vsa_index *index,
                             const vsa_queries *queries,
                             int domaximaluniquematch,

@@ -1921,6 +1921,8 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
 }
 
+#include "approx_search.inc"
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -2080,6 +2082,65 @@ extern "C" int vsa_findcompletematches(const vsa_index *index,
     VSA_ERROR("patternlength=%lu must be >= %lu=prefixlen",
               (unsigned long) queries->hlength[qlimit],
               (unsigned long) index->pl);
+    return -2;
+  }
+  return 0;
+}
+
+extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
+                                             const vsa_queries *queries,
+                                             int doedist, uint64_t distvalue,
+                                             int percent,
+                                             vsa_result **result)
+{
+  if (index == nullptr || queries == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findapproxcompletematches: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (index->bck == nullptr)
+  {
+    VSA_ERROR("table bck is not loaded");
+    return -3;
+  }
+  if (index->numofchars != 4)
+  {
+    VSA_ERROR("approximate search on alphabets of %lu symbols is not covered "
+              "by the GPU engine", (unsigned long) index->numofchars);
+    return VSA_NOT_COVERED;
+  }
+  ApmPlan plan;
+  int rc = apm_plan(index, queries, doedist != 0, distvalue, percent != 0,
+                    plan);
+  if (rc != 0)
+  {
+    return rc;
+  }
+  if (plan.allexact)
+  {
+    // approxcompl.c:167-176: threshold 0 is the exact search
+    return vsa_findcompletematches(index, queries, result);
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  rc = (index->isize == 4)
+           ? run_approx<uint32_t>(index, queries, doedist != 0, plan, res)
+           : run_approx<uint64_t>(index, queries, doedist != 0, plan, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  if (plan.qlimit < queries->nq)
+  {
+    // splitesaapm.c:496-501; the queries before it have been answered
+    VSA_ERROR("threshold=%lu>=%lu=patternlen not allowed",
+              (unsigned long) plan.failk, (unsigned long) plan.failm);
     return -2;
   }
   return 0;
