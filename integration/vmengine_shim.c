@@ -153,6 +153,17 @@ static int getgpuqueries(Multiseq *multiseq, BOOL rcmode,
 
 /* ---- vmatch -complete -q ------------------------------------------------ */
 
+/* length of query sequence number seqnum (kurtz-basic/multiseq.c:129-166) */
+static Uint querylength(Matchstate *matchstate, Uint seqnum)
+{
+  Multiseq *multiseq = matchstate->queryinfo->multiseq;
+  Uint s = (seqnum == 0) ? 0 : multiseq->markpos.spaceUint[seqnum - 1] + 1;
+  Uint e = (seqnum == multiseq->numofsequences - 1)
+               ? multiseq->totallength
+               : multiseq->markpos.spaceUint[seqnum];
+  return e - s;
+}
+
 static int completesink(void *info, const vsa_match *m)
 {
   Matchstate *matchstate = (Matchstate *) info;
@@ -164,6 +175,31 @@ static int completesink(void *info, const vsa_match *m)
   match.distance = 0;
   match.position1 = (Uint) m->dbstart;
   return matchstate->processfinal(matchstate, &match) != 0 ? 1 : 0;
+}
+
+/* edistprocessstartpos / hammingprocessstartpos, approxcompl.c:14-83 */
+typedef struct
+{
+  Matchstate *matchstate;
+  int hamming;
+} Approxsink;
+
+static int approxsink(void *info, const vsa_match *m)
+{
+  Approxsink *sink = (Approxsink *) info;
+  Match match;
+
+  initcompletematchstruct(&match, (Uint) m->queryseq,
+                          /* plen */ 0,
+                          CHECKSHOWPALINDROMIC(sink->matchstate) ? True
+                                                                 : False);
+  match.length2 = querylength(sink->matchstate, (Uint) m->queryseq);
+  match.position1 = (Uint) m->dbstart;
+  match.length1 = (Uint) m->length;
+  match.distance = sink->hamming ? -(Sint) m->querystart
+                                 : (Sint) m->querystart;
+  return sink->matchstate->processfinal(sink->matchstate, &match) != 0 ? 1
+                                                                       : 0;
 }
 
 Sint __wrap_findcompletematches(Virtualtree *virtualtree,
@@ -184,7 +220,12 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
   vsa_queries *queries;
   int rc;
 
-  if (!usegpu() || online || !MPARMEXACTMATCH(&matchparam->maxdist) ||
+  const int approx = !MPARMEXACTMATCH(&matchparam->maxdist);
+
+  /* approximate matching: -e K / -h K and the percent forms (qualint.h:12-13)
+     go to the GPU; "best of" (Qualbestof, initcompl.c:59-77) stays here */
+  if (!usegpu() || online ||
+      (approx && matchparam->maxdist.distinterpretation == Qualbestof) ||
       cpridxpatsearchbundle->handle != NULL || virtualtree->suftab == NULL ||
       virtualtree->bcktab == NULL || virtualtree->lcptab == NULL)
   {
@@ -207,7 +248,33 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
   {
     return (Sint) -2;
   }
-  rc = vsa_findcompletematches_cb(index, queries, completesink, &matchstate);
+  if (approx)
+  {
+    Approxsink sink;
+    sink.matchstate = &matchstate;
+    sink.hamming = MPARMHAMMINGMATCH(&matchparam->maxdist) ? 1 : 0;
+    rc = vsa_findapproxcompletematches_cb(
+        index, queries, MPARMEDISTMATCH(&matchparam->maxdist) ? 1 : 0,
+        (uint64_t) matchparam->maxdist.distvalue,
+        matchparam->maxdist.distinterpretation == Qualpercentaway ? 1 : 0,
+        approxsink, &sink);
+    if (rc == VSA_NOT_COVERED)
+    {
+      /* nothing has been reported yet: the reference's own function takes
+         the whole batch */
+      vsa_queries_free(queries);
+      return __real_findcompletematches(
+          virtualtree, indexormatchfile, queryinfo, rcmode, online,
+          matchparam, bestflag, shownoevalue, showselfpalindromic,
+          selectbundle, procmultiseq, currentdirection, processfinal,
+          cpridxpatsearchbundle, cpridxpatsearchdata, evalues,
+          domatchbuffering);
+    }
+  } else
+  {
+    rc = vsa_findcompletematches_cb(index, queries, completesink,
+                                    &matchstate);
+  }
   vsa_queries_free(queries);
   if (rc != 0)
   {

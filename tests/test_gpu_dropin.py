@@ -41,7 +41,8 @@ def stage(case, wd):
             [m["query"]] if "query" in m else []):
         src = os.path.join(H.GOLDEN, name)
         dst = name[:-3] if name.endswith(".gz") else name
-        dst = dst[len("micro_"):] if dst.startswith("micro_") else dst
+        for prefix in ("micro_", "c5_"):
+            dst = dst[len(prefix):] if dst.startswith(prefix) else dst
         if name.endswith(".gz"):
             with gzip.open(src, "rb") as f, open(wd + "/" + dst, "wb") as g:
                 g.write(f.read())
@@ -56,7 +57,7 @@ MKV = {"largepat": ["-db", "ychrIII.fna"], "micro": ["-db", "db.fna"],
        "grumbach": ["-db", "humhbb.fna"],
        "grumbach_all": ["-indexname", "all", "-db", "humhbb.fna", "-q",
                         "humdystrop.fna"],
-       "c1": ["-db", "genome.fna"]}
+       "c1": ["-db", "genome.fna"], "c5": ["-db", "db.fna"]}
 
 
 def run_gpu_vmatch(args, wd, env=None):
