@@ -53,14 +53,17 @@ def test_gpu_reproduces_reference_approximate_matches(V, case, key):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("doedist", [True, False])
+@pytest.mark.parametrize("doedist,qwild", [(True, True), (True, False),
+                                           (False, False)])
 @pytest.mark.parametrize("m,k", [(100, 2), (150, 2), (64, 1), (33, 1),
-                                 (200, 5), (250, 3), (120, 4)])
-def test_gpu_equals_oracle_on_repeats_and_separators(V, doedist, m, k):
+                                 (200, 5), (250, 3), (120, 4), (90, 3)])
+def test_gpu_equals_oracle_on_repeats_and_separators(V, doedist, qwild, m, k):
     """texts with diverged repeats (many overlapping regions), several
     sequences (separators inside regions) and wildcards; reads with up to
-    k + 1 edit operations"""
-    rng = np.random.default_rng(1000 * m + 10 * k + int(doedist))
+    k + 1 edit operations.  qwild: some reads carry a wildcard, which sends
+    an edit distance batch through the region scan (Myers columns) instead
+    of the banded alignment of the candidate start positions"""
+    rng = np.random.default_rng(1000 * m + 10 * k + int(doedist) + 2 * qwild)
     seqs = []
     for s in range(3):
         L = 20000
@@ -90,7 +93,7 @@ def test_gpu_equals_oracle_on_repeats_and_separators(V, doedist, m, k):
                 q = np.delete(q, x)
             else:
                 q = np.insert(q, x, rng.integers(0, 4))
-        if doedist and i % 50 == 0:
+        if qwild and i % 50 == 0:
             q[int(rng.integers(0, len(q)))] = H.WILDCARD
         qs.append(q.astype(np.uint8))
     q = H.Queries.from_list(qs)
@@ -147,3 +150,15 @@ def test_callback_variant_replays_in_order(V):
     want = V.findapproxcompletematches(gi, gpu_queries(V, q), True, 2).fetch()
     rc, got = V.findapproxcompletematches_cb(gi, gpu_queries(V, q), True, 2)
     assert rc == 0 and np.array_equal(np.array(got, dtype=want.dtype), want)
+
+
+def test_region_scan_and_banded_alignment_agree(V, monkeypatch):
+    """the two ways of finding the start positions (VSA_APM_SCAN=1 forces
+    the region scan) on the full c1 batch"""
+    idx, q = H.load_case("c1")
+    gi = gpu_index(V, "c1")
+    a = V.findapproxcompletematches(gi, gpu_queries(V, q), True, 2).fetch()
+    monkeypatch.setenv("VSA_APM_SCAN", "1")
+    b = V.findapproxcompletematches(gi, gpu_queries(V, q), True, 2).fetch()
+    assert len(a) == M["c1"]["runs"]["approx_e2"]["lines"]
+    assert np.array_equal(a, b)
