@@ -191,6 +191,7 @@ typedef struct
   double search_kernel_ms; /* HIP-event time of the dominant search kernel */
   double total_device_ms;  /* HIP-event time of the whole call            */
   double anchor_ms;        /* -mum: anchor pass + work list (0 if unused)  */
+  uint64_t kernel_searches; /* of those: by the dominant search kernel     */
 } vsa_stats;
 
 uint64_t vsa_result_count(const vsa_result *result);

@@ -68,7 +68,8 @@ class Stats(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sumlength", C.c_uint64),
                 ("searches", C.c_uint64), ("candidates", C.c_uint64),
                 ("search_kernel_ms", C.c_double),
-                ("total_device_ms", C.c_double), ("anchor_ms", C.c_double)]
+                ("total_device_ms", C.c_double), ("anchor_ms", C.c_double),
+                ("kernel_searches", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

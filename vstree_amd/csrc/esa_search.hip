@@ -631,6 +631,243 @@ k_expand_worklist(const uint32_t *__restrict__ count,
   }
 }
 
+// ---- MUM work plan -------------------------------------------------------
+//
+// e(j) = j + (length of the longest match of the query suffix at offset j)
+// never decreases with j, and an offset whose e equals that of the offset in
+// front of it cannot be a MUM candidate: its longest match is the one of its
+// predecessor moved by one symbol, so it is either not unique or not left
+// maximal (leftrightmaximaluniquematch / PROCESSSUFFIX, fquery.c:54-81,
+// 297-386; the reference's default algorithm 2 rides the same suffix links,
+// matchsub.c:400-491).  So after the suffix at offset j has been located,
+// with E = e(j): if the suffix at jp = E + 1 - l (the last one whose first l
+// symbols end at E) also stops at E, every offset in (j, jp] stops at E and
+// is dead; the offsets (jp, E] have to be searched, and E + 1 starts afresh.
+// A read with one substitution at x costs 1 + l searches instead of x + 2.
+//
+// A plan is at most VSA_PLAN_RANGES ranges of offsets per query, 16 bits
+// each for first offset and length.
+
+#define VSA_PLAN_RANGES 4
+#define VSA_PLAN_ROUNDS 3
+
+struct PlanRanges
+{
+  uint32_t r[VSA_PLAN_RANGES]; // first | length << 16
+};
+
+__device__ __forceinline__ void plan_add(PlanRanges &pr, uint32_t &nr,
+                                         uint32_t first, uint32_t last)
+{
+  // [first, last], behind everything added so far
+  if (first > last)
+  {
+    return;
+  }
+  if (nr > 0)
+  {
+    const uint32_t pf = pr.r[nr - 1] & 0xFFFFu, pl = pr.r[nr - 1] >> 16;
+    if (pf + pl == first || nr == VSA_PLAN_RANGES)
+    {
+      // contiguous, or no slot left: extend the last range up to here
+      // (searching a dead offset is harmless, it reports nothing)
+      pr.r[nr - 1] = pf | ((last - pf + 1) << 16);
+      return;
+    }
+  }
+  pr.r[nr++] = first | ((last - first + 1) << 16);
+}
+
+// default plan of every query: offsets 0 .. need-1
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_plan_default(const uint32_t *__restrict__ count, uint64_t nq,
+               PlanRanges *__restrict__ plan)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (q < nq)
+  {
+    PlanRanges pr;
+    pr.r[0] = count[q] << 16;
+#pragma unroll
+    for (int i = 1; i < VSA_PLAN_RANGES; i++)
+    {
+      pr.r[i] = 0;
+    }
+    plan[q] = pr;
+  }
+}
+
+// one work-item per listed query (those with many offsets to search)
+template <typename IDX, bool DEEP>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
+           const uint32_t *__restrict__ list, uint64_t nlist,
+           uint32_t searchlength, uint32_t *__restrict__ count,
+           PlanRanges *__restrict__ plan)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  bool busy = t < nlist;
+  uint64_t q = 0;
+  uint32_t need = 0, j = 0, nr = 0;
+  const uint32_t qlen = qs.uniformlen;
+  const uint8_t *qstart = qs.symbols;
+  PlanRanges pr;
+
+#pragma unroll
+  for (int i = 0; i < VSA_PLAN_RANGES; i++)
+  {
+    pr.r[i] = 0;
+  }
+  if (busy)
+  {
+    q = list[t];
+    need = count[q];
+    qstart = qs.dense ? qs.symbols + q * qs.uniformlen
+                      : qs.symbols + qs.start[q];
+  }
+  for (int round = 0; round < VSA_PLAN_ROUNDS && __any(busy); round++)
+  {
+    // A: the suffix at offset j
+    uint32_t maxlcp = 0, maxlcp2 = 0;
+    uint64_t witness = 0;
+    bool have = false, have2 = false;
+    if (busy && need - j <= 2)
+    {
+      plan_add(pr, nr, j, need - 1); // nothing to gain any more
+      busy = false;
+    }
+    if constexpr (DEEP)
+    {
+      DeepHit hit;
+      const int st = vsa_locate_deep(ix, busy, qstart + j, qlen - j, maxlcp,
+                                     witness, hit);
+      if (st == VSA_LOC_SLOW)
+      {
+        have = vsa_locate_reference(ix, qstart + j, qlen - j, maxlcp, witness);
+      } else
+      {
+        have = st == VSA_LOC_FOUND;
+      }
+    } else
+    {
+      if (busy)
+      {
+        have = vsa_locate_reference(ix, qstart + j, qlen - j, maxlcp, witness);
+      }
+    }
+    uint32_t E = 0, jp = 0;
+    bool probe = false;
+    if (busy)
+    {
+      plan_add(pr, nr, j, j);
+      if (!have)
+      {
+        // fewer than prefixlength symbols match: no exact E; the offsets
+        // up to there are searched, the next round starts behind them
+        const uint32_t last = (j + ix.pl - 1 < need - 1) ? j + ix.pl - 1
+                                                         : need - 1;
+        plan_add(pr, nr, j + 1, last);
+        j = last + 1;
+        busy = j < need;
+      } else
+      {
+        E = j + maxlcp;
+        if (E >= qlen)
+        {
+          busy = false; // matches to the end: every later offset is dead
+        } else
+        {
+          probe = E + 1 >= searchlength + j + 3 &&
+                  E + 1 - searchlength < need;
+          jp = probe ? E + 1 - searchlength : 0;
+        }
+      }
+    }
+    // B: the probe at jp
+    const bool doprobe = busy && have && probe;
+    if constexpr (DEEP)
+    {
+      DeepHit hit;
+      const int st = vsa_locate_deep(ix, doprobe, qstart + jp, qlen - jp,
+                                     maxlcp2, witness, hit);
+      if (st == VSA_LOC_SLOW)
+      {
+        have2 = vsa_locate_reference(ix, qstart + jp, qlen - jp, maxlcp2,
+                                     witness);
+      } else
+      {
+        have2 = st == VSA_LOC_FOUND;
+      }
+    } else
+    {
+      if (doprobe)
+      {
+        have2 = vsa_locate_reference(ix, qstart + jp, qlen - jp, maxlcp2,
+                                     witness);
+      }
+    }
+    if (busy && have)
+    {
+      const bool dead = doprobe && have2 && jp + maxlcp2 == E;
+      const uint32_t first = dead ? jp + 1 : j + 1;
+      const uint32_t last = (E < need - 1) ? E : need - 1;
+      plan_add(pr, nr, first, last);
+      j = E + 1;
+      busy = j < need;
+    }
+  }
+  if (t < nlist)
+  {
+    if (busy)
+    {
+      plan_add(pr, nr, j, need - 1); // out of rounds: search the rest
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (int i = 0; i < VSA_PLAN_RANGES; i++)
+    {
+      total += pr.r[i] >> 16;
+    }
+    plan[q] = pr;
+    count[q] = total;
+  }
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_expand_plan(const PlanRanges *__restrict__ plan,
+              const uint64_t *__restrict__ wbase, uint64_t nq,
+              uint32_t *__restrict__ wlq, uint32_t *__restrict__ wloff)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (q >= nq)
+  {
+    return;
+  }
+  const PlanRanges pr = plan[q];
+  uint64_t b = wbase[q];
+#pragma unroll
+  for (int i = 0; i < VSA_PLAN_RANGES; i++)
+  {
+    const uint32_t first = pr.r[i] & 0xFFFFu, len = pr.r[i] >> 16;
+    for (uint32_t j = 0; j < len; j++)
+    {
+      wlq[b] = (uint32_t) q;
+      wloff[b] = first + j;
+      b++;
+    }
+  }
+}
+
+struct PlanWanted
+{
+  const uint32_t *count;
+  uint32_t threshold;
+  __device__ bool operator()(uint32_t q) const
+  {
+    return count[q] > threshold;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // K4: MUM candidates -> MUMs (kurtz/cleanMUMcand.c:55-118)
 // ---------------------------------------------------------------------------
@@ -1557,7 +1794,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   }
   tall.start();
   // MUM modes over batches of equal-length queries: anchor pass + work list
-  DevBuf wcount, wbase, wlq, wloff, wtemp;
+  DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist;
+  uint64_t plansearches = 0;
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
@@ -1586,6 +1824,59 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipGetLastError());
     size_t tb = 0;
+    // work plan for the queries that still have many offsets (see
+    // k_mum_plan); the quirk of the reference's uniqueness test for
+    // lcp >= 255 (fquery.c:352) keeps longer queries out
+    const bool planned = qs.uniformlen < 255 && perquery < 0xFFFFu &&
+                         (index->tune & 4u) == 0;
+    if (planned)
+    {
+      uint64_t nlist = 0;
+      PlanWanted wanted{wcount.as<uint32_t>(), searchlength + 6};
+      if (wplan.alloc(nq * sizeof(PlanRanges)) || wlist.alloc(nq * 4) ||
+          wnlist.alloc(8))
+      {
+        return -100;
+      }
+      k_plan_default<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          wcount.as<uint32_t>(), nq, wplan.as<PlanRanges>());
+      VSA_HIP(hipGetLastError());
+      VSA_HIP(rocprim::select(nullptr, tb,
+                              rocprim::counting_iterator<uint32_t>(0),
+                              wlist.as<uint32_t>(), wnlist.as<uint64_t>(),
+                              (size_t) nq, wanted, stream));
+      if (wtemp.alloc(tb))
+      {
+        return -100;
+      }
+      VSA_HIP(rocprim::select(wtemp.p, tb,
+                              rocprim::counting_iterator<uint32_t>(0),
+                              wlist.as<uint32_t>(), wnlist.as<uint64_t>(),
+                              (size_t) nq, wanted, stream));
+      VSA_HIP(hipMemcpyAsync(&nlist, wnlist.p, 8, hipMemcpyDeviceToHost,
+                             stream));
+      VSA_HIP(hipStreamSynchronize(stream));
+      if (nlist > 0)
+      {
+        if (deepok)
+        {
+          if constexpr (sizeof(IDX) == 4)
+          {
+            k_mum_plan<IDX, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+                ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+                wcount.as<uint32_t>(), wplan.as<PlanRanges>());
+          }
+        } else
+        {
+          k_mum_plan<IDX, false><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+              ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+              wcount.as<uint32_t>(), wplan.as<PlanRanges>());
+        }
+        VSA_HIP(hipGetLastError());
+      }
+      plansearches = 2 * nlist;
+    }
+    tb = 0;
     auto widen = rocprim::make_transform_iterator(
         wcount.as<uint32_t>(),
         [] __device__(uint32_t v) { return (uint64_t) v; });
@@ -1606,16 +1897,24 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     {
       return -100;
     }
-    k_expand_worklist<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-        wcount.as<uint32_t>(), wbase.as<uint64_t>(), nq, wlq.as<uint32_t>(),
-        wloff.as<uint32_t>());
+    if (planned)
+    {
+      k_expand_plan<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          wplan.as<PlanRanges>(), wbase.as<uint64_t>(), nq,
+          wlq.as<uint32_t>(), wloff.as<uint32_t>());
+    } else
+    {
+      k_expand_worklist<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          wcount.as<uint32_t>(), wbase.as<uint64_t>(), nq,
+          wlq.as<uint32_t>(), wloff.as<uint32_t>());
+    }
     VSA_HIP(hipGetLastError());
     tanchor.stop();
     VSA_HIP(hipStreamSynchronize(stream));
     anchorms = tanchor.ms();
     dwlq = wlq.as<uint32_t>();
     dwloff = wloff.as<uint32_t>();
-    res->stats.searches = nwork + nq;
+    res->stats.searches = nwork + nq + plansearches;
   }
   std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
   DevBuf doff, rawout, rawkeys;
@@ -1765,6 +2064,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   res->stats.count = res->count;
   res->stats.search_kernel_ms = searchms;
   res->stats.anchor_ms = anchorms;
+  res->stats.kernel_searches = nwork;
   res->stats.total_device_ms = tall.ms();
   return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
 }
