@@ -159,6 +159,17 @@ int vsa_queries_from_host(const uint8_t *symbols, uint64_t nsymbols,
 int vsa_queries_from_device(const void *device_symbols, uint64_t nq,
                             uint32_t m, int device, vsa_queries **queries);
 
+/* vmatch -p: the batch with every sequence replaced by its reverse
+   complement (symbol 3 - c, wildcards stay), what copymultiseqRC
+   (kurtz-basic/readmulti.c:93-125) stores in Multiseq.rcsequence and the
+   engine receives with rcmode = True (Vmatch/runquery.c:179-279).  A symbol
+   above 3 that is not a wildcard is the reference's error "reverse
+   complement of %lu undefined" (readmulti.c:45-49).  Match positions inside
+   the query refer to the reverse complement; the flip back to the forward
+   strand is the sink's (Vmatch/procfinal.c:152-168). */
+int vsa_queries_reverse_complement(const vsa_queries *queries,
+                                   vsa_queries **rcqueries);
+
 void vsa_queries_free(vsa_queries *queries);
 
 /* queryseq of every match = index in the batch + offset: a rank that holds

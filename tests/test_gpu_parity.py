@@ -320,3 +320,42 @@ def test_mum_filter_in_dbstart_ranges_equals_whole_filter(V):
                         - 1)
         V.device_free(dp)
     assert np.array_equal(np.concatenate(pieces), want)
+
+
+def host_reverse_complement(q):
+    """copymultiseqRC (kurtz-basic/readmulti.c:93-125) in numpy"""
+    sym = q.symbols.copy()
+    for s, l in zip(q.start, q.length):
+        s, l = int(s), int(l)
+        seg = q.symbols[s:s + l][::-1]
+        sym[s:s + l] = np.where(seg == H.WILDCARD, H.WILDCARD, 3 - seg)
+    return H.Queries(sym, q.start, q.length)
+
+
+@pytest.mark.parametrize("case", ["c1", "micro", "grumbach"])
+def test_reverse_complement_queries(V, case):
+    """vmatch -p at library level: the batch the engine receives with
+    rcmode = True; checked against the oracle run on reverse complements
+    made on the host (and, for c1, against the number of P lines the
+    reference printed for -complete -d -p)"""
+    idx, q = H.load_case(case)
+    gi = gpu_index(V, case)
+    rq = gpu_queries(V, q).reverse_complement()
+    hq = host_reverse_complement(q)
+    L = max(idx.prefixlength, 14 if case != "micro" else 2)
+    got = V.findquerymatches(gi, rq, L, mum=True, cand=True).fetch()
+    assert np.array_equal(got, H.oracle_querymatches(idx, hq, L, mum=True,
+                                                     cand=True, speedup=0))
+    if q.length.min() >= idx.prefixlength:
+        both = V.findcompletematches(gi, rq).fetch()
+        assert np.array_equal(both, H.oracle_complete(idx, hq))
+        if case == "c1":
+            fwd = V.findcompletematches(gi, gpu_queries(V, q)).count
+            assert fwd + len(both) == M["c1"]["runs"]["complete_dp"]["lines"]
+
+
+def test_reverse_complement_of_a_protein_batch_is_the_reference_error(V):
+    q = H.Queries.from_list([[0, 1, 2, 3], [0, 7, 2]])
+    with pytest.raises(V.VsaError) as ei:
+        gpu_queries(V, q).reverse_complement()
+    assert "reverse complement of 7 undefined" in str(ei.value)

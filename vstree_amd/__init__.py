@@ -108,6 +108,7 @@ def _load():
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
         "vsa_queries_from_device": (I, [V, U64, U32, I, PP]),
+        "vsa_queries_reverse_complement": (I, [V, PP]),
         "vsa_queries_free": (None, [V]),
         "vsa_queries_set_offset": (I, [V, U64]),
         "vsa_result_count": (U64, [V]),
@@ -280,6 +281,12 @@ class Queries:
 
     def set_offset(self, offset):
         _check(lib.vsa_queries_set_offset(self._h, int(offset)))
+
+    def reverse_complement(self):
+        """vmatch -p: every sequence reversed and complemented on its own"""
+        h = C.c_void_p()
+        _check(lib.vsa_queries_reverse_complement(self._h, C.byref(h)))
+        return Queries(h, self.nq)
 
     def close(self):
         if self._h:

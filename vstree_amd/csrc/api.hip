@@ -561,6 +561,100 @@ extern "C" int vsa_queries_from_device(const void *device_symbols,
   return 0;
 }
 
+// copymultiseqRC, kurtz-basic/readmulti.c:93-125: every sequence reversed
+// and complemented on its own, in place of the forward sequence
+__global__ void __launch_bounds__(256)
+k_reverse_complement(const uint8_t *__restrict__ in,
+                     const uint64_t *__restrict__ start,
+                     const uint64_t *__restrict__ length, uint64_t nq,
+                     uint8_t *__restrict__ out, uint32_t *__restrict__ bad)
+{
+  // one wavefront per sequence, lanes stride over its symbols
+  const uint64_t q = ((uint64_t) blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (q >= nq)
+  {
+    return;
+  }
+  const uint64_t s = start[q], len = length[q];
+  for (uint64_t i = lane; i < len; i += 64)
+  {
+    const uint8_t c = in[s + len - 1 - i];
+    uint8_t r;
+    if (c == VSA_WILDCARD)
+    {
+      r = (uint8_t) VSA_WILDCARD;
+    } else if (c > 3)
+    {
+      r = c; // readmulti.c:45-49: "reverse complement of %lu undefined"
+      atomicMax(bad, (uint32_t) c + 1);
+    } else
+    {
+      r = (uint8_t) (3 - c);
+    }
+    out[s + i] = r;
+  }
+}
+
+extern "C" int vsa_queries_reverse_complement(const vsa_queries *q,
+                                              vsa_queries **rcqueries)
+{
+  if (q == nullptr || rcqueries == nullptr)
+  {
+    VSA_ERROR("vsa_queries_reverse_complement: NULL argument");
+    return -1;
+  }
+  *rcqueries = nullptr;
+  if (vsa_set_device(q->device) != 0)
+  {
+    return -100;
+  }
+  vsa_queries *r = new vsa_queries;
+  r->device = q->device;
+  r->nq = q->nq;
+  r->nsymbols = q->nsymbols;
+  r->seqoffset = q->seqoffset;
+  r->symbols = nullptr;
+  r->start = r->length = nullptr;
+  r->hlength = q->hlength;
+  r->minlength = q->minlength;
+  r->maxlength = q->maxlength;
+  r->uniform = q->uniform;
+  r->dense = q->dense;
+  *rcqueries = r;
+  uint32_t *dbad = nullptr, hbad = 0;
+  VSA_HIP(hipMalloc((void **) &r->symbols, r->nsymbols + VSA_QUERY_BACKPAD));
+  VSA_HIP(hipMalloc((void **) &r->start, (r->nq + 1) * 8));
+  VSA_HIP(hipMalloc((void **) &r->length, (r->nq + 1) * 8));
+  VSA_HIP(hipMalloc((void **) &dbad, 4));
+  VSA_HIP(hipMemset(dbad, 0, 4));
+  // separators between the sequences and the padding stay what they are
+  VSA_HIP(hipMemcpy(r->symbols, q->symbols,
+                    r->nsymbols + VSA_QUERY_BACKPAD,
+                    hipMemcpyDeviceToDevice));
+  VSA_HIP(hipMemcpy(r->start, q->start, (r->nq + 1) * 8,
+                    hipMemcpyDeviceToDevice));
+  VSA_HIP(hipMemcpy(r->length, q->length, (r->nq + 1) * 8,
+                    hipMemcpyDeviceToDevice));
+  if (r->nq > 0)
+  {
+    k_reverse_complement<<<(unsigned int) ((r->nq * 64 + 255) / 256), 256>>>(
+        q->symbols, q->start, q->length, r->nq, r->symbols, dbad);
+    VSA_HIP(hipGetLastError());
+  }
+  VSA_HIP(hipMemcpy(&hbad, dbad, 4, hipMemcpyDeviceToHost));
+  (void) hipFree(dbad);
+  if (hbad != 0)
+  {
+    VSA_ERROR("reverse complement of %lu undefined",
+              (unsigned long) (hbad - 1));
+    vsa_queries_free(r);
+    *rcqueries = nullptr;
+    return -2;
+  }
+  return 0;
+}
+
 extern "C" int vsa_queries_set_offset(vsa_queries *q, uint64_t offset)
 {
   if (q == nullptr)
