@@ -649,7 +649,8 @@ k_expand_worklist(const uint32_t *__restrict__ count,
 // each for first offset and length.
 
 #define VSA_PLAN_RANGES 4
-#define VSA_PLAN_ROUNDS 3
+#define VSA_PLAN_ROUNDS 6
+#define VSA_PLAN_UNKNOWN 0xFFFFFFFFu
 
 struct PlanRanges
 {
@@ -702,13 +703,16 @@ template <typename IDX, bool DEEP>
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
            const uint32_t *__restrict__ list, uint64_t nlist,
-           uint32_t searchlength, uint32_t *__restrict__ count,
-           PlanRanges *__restrict__ plan)
+           uint32_t searchlength, const uint32_t *__restrict__ firste,
+           uint32_t *__restrict__ count, PlanRanges *__restrict__ plan)
 {
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
   bool busy = t < nlist;
   uint64_t q = 0;
   uint32_t need = 0, j = 0, nr = 0;
+  // offset 0 has been located by k_mum_first: its e is known, and it is
+  // not searched again
+  uint32_t e0 = VSA_PLAN_UNKNOWN;
   const uint32_t qlen = qs.uniformlen;
   const uint8_t *qstart = qs.symbols;
   PlanRanges pr;
@@ -724,6 +728,10 @@ k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
     need = count[q];
     qstart = qs.dense ? qs.symbols + q * qs.uniformlen
                       : qs.symbols + qs.start[q];
+    if (firste != nullptr)
+    {
+      e0 = firste[q];
+    }
   }
   for (int round = 0; round < VSA_PLAN_ROUNDS && __any(busy); round++)
   {
@@ -731,7 +739,8 @@ k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
     uint32_t maxlcp = 0, maxlcp2 = 0;
     uint64_t witness = 0;
     bool have = false, have2 = false;
-    if (busy && need - j <= 2)
+    const bool known = round == 0 && e0 != VSA_PLAN_UNKNOWN;
+    if (busy && !known && need - j <= 2)
     {
       plan_add(pr, nr, j, need - 1); // nothing to gain any more
       busy = false;
@@ -739,8 +748,8 @@ k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
     if constexpr (DEEP)
     {
       DeepHit hit;
-      const int st = vsa_locate_deep(ix, busy, qstart + j, qlen - j, maxlcp,
-                                     witness, hit);
+      const int st = vsa_locate_deep(ix, busy && !known, qstart + j, qlen - j,
+                                     maxlcp, witness, hit);
       if (st == VSA_LOC_SLOW)
       {
         have = vsa_locate_reference(ix, qstart + j, qlen - j, maxlcp, witness);
@@ -750,16 +759,24 @@ k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
       }
     } else
     {
-      if (busy)
+      if (busy && !known)
       {
         have = vsa_locate_reference(ix, qstart + j, qlen - j, maxlcp, witness);
       }
+    }
+    if (known)
+    {
+      have = true;
+      maxlcp = e0;
     }
     uint32_t E = 0, jp = 0;
     bool probe = false;
     if (busy)
     {
-      plan_add(pr, nr, j, j);
+      if (!known)
+      {
+        plan_add(pr, nr, j, j);
+      }
       if (!have)
       {
         // fewer than prefixlength symbols match: no exact E; the offsets
@@ -857,6 +874,113 @@ k_expand_plan(const PlanRanges *__restrict__ plan,
     }
   }
 }
+
+
+// The first pass of a MUM batch: offset 0 of every query, located with the
+// whole query.  A query that matches completely is finished here: e(0) is
+// the end of the query, so no later offset can be a candidate (see above),
+// and offset 0 is one iff its match is unique -- its left neighbour is the
+// start of the query, which PROCESSSUFFIX treats as left maximal
+// (fquery.c:54-81).  That is one search for an exact read instead of two
+// (last offset + offset 0) and a backward walk.  For the others e(0) goes to
+// the work plan.
+template <typename IDX, bool DEEP>
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_mum_first(const DevIndex<IDX> ix, const DevQueries qs, uint32_t perquery,
+            uint32_t searchlength, uint32_t *__restrict__ count,
+            uint32_t *__restrict__ firste, uint32_t *__restrict__ fmlen,
+            uint64_t *__restrict__ fmdb)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const bool active = q < qs.nq && perquery > 0;
+  const uint32_t qlen = qs.uniformlen;
+  const uint8_t *qptr = qs.symbols;
+  uint32_t maxlcp = 0;
+  uint64_t witness = 0;
+  bool have = false, fast = false;
+  DeepHit hit;
+
+  if (active)
+  {
+    qptr = qs.dense ? qs.symbols + q * qs.uniformlen
+                    : qs.symbols + qs.start[q];
+  }
+  if constexpr (DEEP)
+  {
+    const int st = vsa_locate_deep(ix, active, qptr, qlen, maxlcp, witness,
+                                   hit);
+    if (st == VSA_LOC_SLOW)
+    {
+      have = vsa_locate_reference(ix, qptr, qlen, maxlcp, witness);
+    } else
+    {
+      have = st == VSA_LOC_FOUND;
+      fast = have && maxlcp < 255;
+    }
+  } else
+  {
+    if (active)
+    {
+      have = vsa_locate_reference(ix, qptr, qlen, maxlcp, witness);
+    }
+  }
+  if (!active)
+  {
+    return;
+  }
+  uint32_t len = 0;
+  uint64_t db = 0;
+  if (have && maxlcp >= searchlength)
+  {
+    bool unique;
+    if (fast)
+    {
+      const uint32_t lcpw = (uint32_t) (hit.ew >> 32) & 0xFFu;
+      unique = (witness == 0 || lcpw < maxlcp) &&
+               (witness + 1 > ix.n - 1 || hit.lcpnext < maxlcp);
+      db = hit.ew & 0xFFFFFFFFull;
+    } else
+    {
+      unique = vsa_mum_candidate<IDX, DEEP>(ix, maxlcp, witness);
+      db = vsa_sufstart<IDX, DEEP>(ix, witness);
+    }
+    len = unique ? maxlcp : 0;
+  }
+  fmlen[q] = len;
+  fmdb[q] = db;
+  firste[q] = have ? maxlcp : VSA_PLAN_UNKNOWN;
+  count[q] = (have && maxlcp >= qlen) ? 0 : perquery;
+}
+
+// candidates of the first pass -> behind the matches of the search kernel,
+// with the sort key of work-item (query, offset 0)
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_append_first(const uint32_t *__restrict__ fmlen,
+               const uint64_t *__restrict__ fmdb,
+               const uint32_t *__restrict__ slot, uint64_t nq,
+               uint32_t perquery, uint64_t seqoffset, uint64_t base,
+               vsa_match *__restrict__ out, uint64_t *__restrict__ outkey)
+{
+  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (q < nq && fmlen[q] != 0)
+  {
+    vsa_match m;
+    m.length = fmlen[q];
+    m.dbstart = fmdb[q];
+    m.queryseq = q + seqoffset;
+    m.querystart = 0;
+    out[base + slot[q]] = m;
+    outkey[base + slot[q]] = q * perquery;
+  }
+}
+
+struct NonZeroToU32
+{
+  __device__ uint32_t operator()(uint32_t v) const
+  {
+    return v != 0 ? 1u : 0u;
+  }
+};
 
 struct PlanWanted
 {
@@ -1794,8 +1918,10 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   }
   tall.start();
   // MUM modes over batches of equal-length queries: anchor pass + work list
-  DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist;
-  uint64_t plansearches = 0;
+  DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist, wfirste,
+      wfmlen, wfmdb, wfslot;
+  uint64_t plansearches = 0, nfirst = 0;
+  bool firstpass = false;
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
@@ -1810,7 +1936,37 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     tanchor.start();
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
-    if (deepok)
+    // work plan (see k_mum_plan); the quirk of the reference's uniqueness
+    // test for lcp >= 255 (fquery.c:352) keeps longer queries out
+    const bool planned = qs.uniformlen < 255 && perquery < 0xFFFFu &&
+                         (index->tune & 4u) == 0;
+    // planned batches start with offset 0 (k_mum_first), the others with the
+    // anchor pass from the last offset
+    firstpass = planned && (index->tune & 8u) == 0;
+    if (firstpass)
+    {
+      if (wfirste.alloc(nq * 4) || wfmlen.alloc(nq * 4) ||
+          wfmdb.alloc(nq * 8))
+      {
+        return -100;
+      }
+      if (deepok)
+      {
+        if constexpr (sizeof(IDX) == 4)
+        {
+          k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+              ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+              wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+              wfmdb.as<uint64_t>());
+        }
+      } else
+      {
+        k_mum_first<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+            ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+            wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+            wfmdb.as<uint64_t>());
+      }
+    } else if (deepok)
     {
       if constexpr (sizeof(IDX) == 4)
       {
@@ -1824,15 +1980,13 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipGetLastError());
     size_t tb = 0;
-    // work plan for the queries that still have many offsets (see
-    // k_mum_plan); the quirk of the reference's uniqueness test for
-    // lcp >= 255 (fquery.c:352) keeps longer queries out
-    const bool planned = qs.uniformlen < 255 && perquery < 0xFFFFu &&
-                         (index->tune & 4u) == 0;
     if (planned)
     {
       uint64_t nlist = 0;
-      PlanWanted wanted{wcount.as<uint32_t>(), searchlength + 6};
+      // after the anchor pass only queries with many offsets left are worth
+      // a plan; after the first pass every unfinished query gets one
+      PlanWanted wanted{wcount.as<uint32_t>(),
+                        firstpass ? 0u : searchlength + 6};
       if (wplan.alloc(nq * sizeof(PlanRanges)) || wlist.alloc(nq * 4) ||
           wnlist.alloc(8))
       {
@@ -1864,12 +2018,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           {
             k_mum_plan<IDX, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
                 ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+                firstpass ? wfirste.as<uint32_t>() : nullptr,
                 wcount.as<uint32_t>(), wplan.as<PlanRanges>());
           }
         } else
         {
           k_mum_plan<IDX, false><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
               ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+              firstpass ? wfirste.as<uint32_t>() : nullptr,
               wcount.as<uint32_t>(), wplan.as<PlanRanges>());
         }
         VSA_HIP(hipGetLastError());
@@ -1963,11 +2119,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }                                                                         \
   } while (0)
     // deep locate needs the deep prefix to fit into every search
-    bool deep = false;
+    bool deep = nwork == 0; // nothing left to search: no launch at all
     if constexpr (sizeof(IDX) == 4)
     {
-      deep = deepok;
-      if (deep)
+      deep = deep || deepok;
+      if (deep && nwork > 0)
       {
         if (domum)
         {
@@ -2016,19 +2172,61 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
               (unsigned long long) maxshard, (unsigned long long) shardcap);
     return -5;
   }
-  if (needed > 0)
+  if (firstpass)
   {
-    if (out.alloc(needed * sizeof(vsa_match)) || keys.alloc(needed * 8))
+    // slots of the first-pass candidates behind the kernel's matches
+    const uint64_t nq = queries->nq;
+    size_t tb = 0;
+    uint32_t lastslot = 0, lastlen = 0;
+    auto flag = rocprim::make_transform_iterator(wfmlen.as<uint32_t>(),
+                                                 NonZeroToU32());
+    if (wfslot.alloc(nq * 4))
     {
       return -100;
     }
-    VSA_HIP(hipMemcpyAsync(doff.p, hoff.data(), nshards * 8,
-                           hipMemcpyHostToDevice, stream));
-    k_compact_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
-        rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
-        cursor.as<unsigned long long>(), doff.as<uint64_t>(),
-        out.as<vsa_match>(), keys.as<uint64_t>());
-    VSA_HIP(hipGetLastError());
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, flag, wfslot.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) nq,
+                                    rocprim::plus<uint32_t>(), stream));
+    if (wtemp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, flag, wfslot.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) nq,
+                                    rocprim::plus<uint32_t>(), stream));
+    VSA_HIP(hipMemcpyAsync(&lastslot, wfslot.as<uint32_t>() + nq - 1, 4,
+                           hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipMemcpyAsync(&lastlen, wfmlen.as<uint32_t>() + nq - 1, 4,
+                           hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    nfirst = (uint64_t) lastslot + (lastlen != 0 ? 1 : 0);
+  }
+  if (needed + nfirst > 0)
+  {
+    if (out.alloc((needed + nfirst) * sizeof(vsa_match)) ||
+        keys.alloc((needed + nfirst) * 8))
+    {
+      return -100;
+    }
+    if (needed > 0)
+    {
+      VSA_HIP(hipMemcpyAsync(doff.p, hoff.data(), nshards * 8,
+                             hipMemcpyHostToDevice, stream));
+      k_compact_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
+          rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
+          cursor.as<unsigned long long>(), doff.as<uint64_t>(),
+          out.as<vsa_match>(), keys.as<uint64_t>());
+      VSA_HIP(hipGetLastError());
+    }
+    if (nfirst > 0)
+    {
+      k_append_first<<<gridfor(queries->nq), VSA_BLOCK, 0, stream>>>(
+          wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
+          wfslot.as<uint32_t>(), queries->nq, perquery, qs.seqoffset, needed,
+          out.as<vsa_match>(), keys.as<uint64_t>());
+      VSA_HIP(hipGetLastError());
+    }
+    needed += nfirst;
   }
   res->stats.candidates = domum ? needed : 0;
   if (domum && !domumcand)
