@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Summarises the counter passes of scripts/pmc_passes.sh (one rocprofv3
+--pmc run per line of counters, bench.py --steps 1 --warmup 0) into a table
+per kernel, and writes profiles/hbm_traffic.json for the dominant kernel.
+usage: pmc_summary.py gpurun_out/DIR OUT.txt [--traffic profiles/hbm_traffic.json]"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[:58]
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    traffic = sys.argv[4] if len(sys.argv) > 4 else None
+    sums = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in sorted(glob.glob(d + "/p*/*/*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[k][r["Counter_Name"]] += 1
+    counters = sorted({c for k in sums for c in sums[k]})
+    want = [k for k in sums if k.startswith("k_") or "k_" in k]
+    lines = ["rocprofv3 --pmc, one pass per counter group (scripts/"
+             "pmc_passes.sh), python3 bench.py --steps 1 --warmup 0 "
+             "--cpu-sample 0; mean per launch", ""]
+    for k in sorted(want):
+        lines.append(k)
+        for c in counters:
+            if c in sums[k]:
+                lines.append("    %-34s %16.4e   (%d launches)" % (
+                    c, sums[k][c] / launches[k][c], launches[k][c]))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:4]))
+    if traffic:
+        dom = [k for k in sums if k.startswith("k_query_search")]
+        if dom:
+            k = dom[0]
+            mean = {c: sums[k][c] / launches[k][c] for c in sums[k]}
+            j = {"kernel": "k_query_search<uint32_t, MUM, deep, 256>",
+                 "index_bp": 3000000000, "queries": 10000000,
+                 "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
+                 "WRITE_SIZE_KiB": mean.get("WRITE_SIZE"),
+                 "TCC_HIT_sum": mean.get("TCC_HIT_sum"),
+                 "TCC_MISS_sum": mean.get("TCC_MISS_sum"),
+                 "hbm_bytes_per_launch":
+                     (mean.get("FETCH_SIZE", 0) + mean.get("WRITE_SIZE", 0))
+                     * 1024,
+                 "note": "random 8/16-byte reads: TCC_MISS_sum x 64 B = "
+                         "FETCH_SIZE x 1024 (one 64-byte request per L2 "
+                         "miss); the x2 correction of MI355X_MICROARCH.md "
+                         "for wide coalesced streams is not applied",
+                 "round": 1, "source": out}
+            json.dump(j, open(traffic, "w"), indent=1)
+            print(json.dumps(j))
+
+
+if __name__ == "__main__":
+    main()
