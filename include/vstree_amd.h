@@ -370,6 +370,66 @@ int vsa_device_trim(int device);
    denominator cross-check in bench.py) */
 int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);
 
+/* ---- host match sink: from match records to vmatch's output lines ------ */
+
+/*
+  processfinal (Vmatch/procfinal.c:515-637: fetchpositions, convertthematch,
+  assignEvalue, matchokay) and the default output line of
+  vmatchnormaloutmatch (Vmatch/echomatch.c:878-987)
+      len1 seq1 pos1 D|P len2 seq2 pos2 dist evalue score identity
+  for the matches of this path, byte for byte what vmatch prints behind its
+  "# args=" line (tests/test_sink.py: md5 of the lines of every golden run).
+  Host side, no GPU involved; large batches are formatted by several
+  threads, the text comes out in the order of the records.
+  totalquerylength of an index with queries = totallength - (position of
+  the separator in front of the first query sequence) - 1.
+*/
+#define VSA_SINK_COMPLETE       0 /* vsa_findcompletematches              */
+#define VSA_SINK_QUERY          1 /* vsa_findquerymatches (-l, -mum ...)  */
+#define VSA_SINK_SELF           2 /* vsa_findmaximaluniquematches         */
+#define VSA_SINK_APPROX_EDIST   3 /* vsa_findapproxcompletematches, -e    */
+#define VSA_SINK_APPROX_HAMMING 4 /* vsa_findapproxcompletematches, -h    */
+
+/* Vmatch option -> bit of showmode (include/outinfo.h SHOW...) */
+#define VSA_SHOW_ABSOLUTE   1u /* -absolute   */
+#define VSA_SHOW_NODIST     2u /* -nodist     */
+#define VSA_SHOW_NOEVALUE   4u /* -noevalue   */
+#define VSA_SHOW_NOSCORE    8u /* -noscore    */
+#define VSA_SHOW_NOIDENTITY 16u /* -noidentity */
+
+typedef struct
+{
+  int kind;              /* VSA_SINK_...                                  */
+  int palindromic;       /* matches of the reverse-complement pass (-p)   */
+  uint32_t showmode;     /* VSA_SHOW_... bits                             */
+  uint32_t numofchars;   /* alpha.mapsize - 1: E-value match probability  */
+  int threads;           /* formatting threads; 0 = one per processor     */
+  uint64_t leastlength;  /* Matchparam.userdefinedleastlength (-l), or 0  */
+  /* the index (Multiseq of the Virtualtree): */
+  uint64_t totallength, numofsequences;
+  const uint64_t *markpos;      /* numofsequences - 1 separator positions
+                                   (IDX.ssp)                              */
+  uint64_t numofquerysequences; /* sequences of queries INSIDE the index  */
+  uint64_t totalquerylength;    /* their total length (IDX.prj), else 0   */
+  /* the query set (not for VSA_SINK_SELF): sequence i occupies
+     [querystart[i], querystart[i] + querylength[i]) of a Multiseq of
+     querytotallength symbols */
+  uint64_t numofqueries, querytotallength;
+  const uint64_t *querystart, *querylength;
+} vsa_sinkparams;
+
+typedef struct vsa_sink vsa_sink;
+
+int vsa_sink_open(const vsa_sinkparams *params, vsa_sink **sink);
+void vsa_sink_close(vsa_sink *sink);
+/* lines (each ending in a newline) into buffer; returns the bytes written or
+   a negative code */
+int64_t vsa_sink_format(vsa_sink *sink, const vsa_match *matches, uint64_t n,
+                        char *buffer, uint64_t capacity);
+/* the same to a FILE * */
+int vsa_sink_write(vsa_sink *sink, const vsa_match *matches, uint64_t n,
+                   void *file);
+
 #ifdef __cplusplus
 }
 #endif

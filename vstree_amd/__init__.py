@@ -64,6 +64,19 @@ class IndexInfo(C.Structure):
                 ("hasindexedqueries", C.c_int), ("hasbwt", C.c_int)]
 
 
+class SinkParams(C.Structure):
+    _fields_ = [("kind", C.c_int), ("palindromic", C.c_int),
+                ("showmode", C.c_uint32), ("numofchars", C.c_uint32),
+                ("threads", C.c_int),
+                ("leastlength", C.c_uint64), ("totallength", C.c_uint64),
+                ("numofsequences", C.c_uint64), ("markpos", C.c_void_p),
+                ("numofquerysequences", C.c_uint64),
+                ("totalquerylength", C.c_uint64),
+                ("numofqueries", C.c_uint64),
+                ("querytotallength", C.c_uint64),
+                ("querystart", C.c_void_p), ("querylength", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sumlength", C.c_uint64),
                 ("searches", C.c_uint64), ("candidates", C.c_uint64),
@@ -129,6 +142,9 @@ def _load():
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
         "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
         "vsa_findmaximaluniquematches_cb": (I, [V, U64, PROCESSMATCH, V]),
+        "vsa_sink_open": (I, [C.POINTER(SinkParams), PP]),
+        "vsa_sink_close": (None, [V]),
+        "vsa_sink_format": (C.c_int64, [V, V, U64, V, U64]),
         "vsa_splitmix64_at": (U64, [U64, U64]),
         "vsa_synth_genome": (None, [U64, U64, V]),
         "vsa_synth_query_plan": (None, [U64, U64, U64, U32, V, V, V]),
@@ -440,6 +456,61 @@ def findmaximaluniquematches_cb(index, searchlength, stop_after=None):
     rc = lib.vsa_findmaximaluniquematches_cb(index._h, int(searchlength), cb,
                                              None)
     return rc, got
+
+
+# ---- host match sink ------------------------------------------------------
+
+SINK_COMPLETE, SINK_QUERY, SINK_SELF, SINK_APPROX_EDIST, \
+    SINK_APPROX_HAMMING = range(5)
+SHOW_ABSOLUTE, SHOW_NODIST, SHOW_NOEVALUE, SHOW_NOSCORE, SHOW_NOIDENTITY = (
+    1, 2, 4, 8, 16)
+
+
+class Sink:
+    """vmatch's output lines for match records (vsa_sink, host side)."""
+
+    def __init__(self, kind, totallength, markpos, numofchars=4,
+                 querystart=None, querylength=None, querytotallength=0,
+                 numofquerysequences=0, totalquerylength=0, leastlength=0,
+                 palindromic=False, showmode=0, threads=0):
+        self._keep = [np.ascontiguousarray(markpos, np.uint64)]
+        p = SinkParams()
+        p.kind, p.palindromic = int(kind), int(bool(palindromic))
+        p.showmode, p.numofchars = int(showmode), int(numofchars)
+        p.threads = int(threads)
+        p.leastlength, p.totallength = int(leastlength), int(totallength)
+        p.numofsequences = self._keep[0].shape[0] + 1
+        p.markpos = _ptr(self._keep[0]) if self._keep[0].shape[0] else None
+        p.numofquerysequences = int(numofquerysequences)
+        p.totalquerylength = int(totalquerylength)
+        if querystart is not None:
+            qs = np.ascontiguousarray(querystart, np.uint64)
+            ql = np.ascontiguousarray(querylength, np.uint64)
+            self._keep += [qs, ql]
+            p.numofqueries = qs.shape[0]
+            p.querytotallength = int(querytotallength)
+            p.querystart, p.querylength = _ptr(qs), _ptr(ql)
+        self._h = C.c_void_p()
+        _check(lib.vsa_sink_open(C.byref(p), C.byref(self._h)))
+
+    def format(self, matches):
+        """matches: MATCH_DTYPE array -> bytes (one line per match)"""
+        matches = np.ascontiguousarray(matches, MATCH_DTYPE)
+        cap = 192 * (matches.shape[0] + 1)
+        buf = np.empty(cap, np.uint8)
+        n = lib.vsa_sink_format(self._h, _ptr(matches), matches.shape[0],
+                                _ptr(buf), cap)
+        if n < 0:
+            raise VsaError(int(n), messagespace())
+        return buf[:n].tobytes()
+
+    def close(self):
+        if self._h:
+            lib.vsa_sink_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 # ---- synthetic inputs (SURVEY.md section 8d) ------------------------------
