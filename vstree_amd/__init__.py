@@ -145,6 +145,7 @@ def _load():
         "vsa_sink_open": (I, [C.POINTER(SinkParams), PP]),
         "vsa_sink_close": (None, [V]),
         "vsa_sink_format": (C.c_int64, [V, V, U64, V, U64]),
+        "vsa_sink_write": (I, [V, V, U64, V]),
         "vsa_splitmix64_at": (U64, [U64, U64]),
         "vsa_synth_genome": (None, [U64, U64, V]),
         "vsa_synth_query_plan": (None, [U64, U64, U64, U32, V, V, V]),
