@@ -369,6 +369,12 @@ int vsa_device_trim(int device);
 /* measured device-to-device streaming read rate in GB/s (roofline
    denominator cross-check in bench.py) */
 int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);
+/* independent random 8-byte reads over a table of `bytes` bytes, `inflight`
+   (1, 4 or 8) of them issued per work-item before any is used: 10^9 reads
+   per second.  The ceiling for the search kernels, whose traffic is one
+   64-byte sector per read that misses the caches. */
+int vsa_measure_random_read(uint64_t bytes, int inflight, int device,
+                            double *greads);
 
 /* ---- host match sink: from match records to vmatch's output lines ------ */
 

@@ -769,6 +769,93 @@ k_stream_read(const uint4 *__restrict__ p, uint64_t n16,
   }
 }
 
+// independent random 8-byte reads: INFLIGHT loads per work-item are issued
+// before any of them is used, the addresses come from a counter-based
+// generator (no dependence between them) -- the rate the memory system
+// sustains for 64-byte sectors that miss every cache
+template <int INFLIGHT>
+__global__ void __launch_bounds__(256)
+k_random_read(const uint64_t *__restrict__ buf, uint64_t nwords,
+              uint64_t perthread, unsigned long long *__restrict__ sink)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+  uint64_t x = t * 0x9E3779B97F4A7C15ull + 1, acc = 0;
+  for (uint64_t i = 0; i < perthread; i += INFLIGHT)
+  {
+    uint64_t v[INFLIGHT];
+#pragma unroll
+    for (int k = 0; k < INFLIGHT; k++)
+    {
+      x += 0x9E3779B97F4A7C15ull;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      v[k] = buf[z % nwords];
+    }
+#pragma unroll
+    for (int k = 0; k < INFLIGHT; k++)
+    {
+      acc += v[k];
+    }
+  }
+  if (acc == 0x1234567ull)
+  {
+    atomicAdd(sink, 1ull);
+  }
+}
+
+extern "C" int vsa_measure_random_read(uint64_t bytes, int inflight,
+                                       int device, double *greads)
+{
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  void *buf = nullptr;
+  unsigned long long *sink = nullptr;
+  const uint64_t nwords = bytes / 8, threads = 256ull * 256 * 32,
+                 perthread = 64;
+  VSA_HIP(hipMalloc(&buf, nwords * 8 + 16));
+  VSA_HIP(hipMalloc((void **) &sink, 8));
+  VSA_HIP(hipMemset(buf, 1, nwords * 8));
+  VSA_HIP(hipMemset(sink, 0, 8));
+  hipEvent_t a, b;
+  VSA_HIP(hipEventCreate(&a));
+  VSA_HIP(hipEventCreate(&b));
+  const int reps = 3;
+  for (int r = 0; r <= reps; r++)
+  {
+    if (r == 1)
+    {
+      VSA_HIP(hipEventRecord(a, 0));
+    }
+    if (inflight >= 8)
+    {
+      k_random_read<8><<<(unsigned int) (threads / 256), 256>>>(
+          (const uint64_t *) buf, nwords, perthread, sink);
+    } else if (inflight >= 4)
+    {
+      k_random_read<4><<<(unsigned int) (threads / 256), 256>>>(
+          (const uint64_t *) buf, nwords, perthread, sink);
+    } else
+    {
+      k_random_read<1><<<(unsigned int) (threads / 256), 256>>>(
+          (const uint64_t *) buf, nwords, perthread, sink);
+    }
+  }
+  VSA_HIP(hipEventRecord(b, 0));
+  VSA_HIP(hipEventSynchronize(b));
+  float ms = 0;
+  VSA_HIP(hipEventElapsedTime(&ms, a, b));
+  *greads = (double) threads * perthread * reps / ((double) ms * 1e-3) / 1e9;
+  (void) hipEventDestroy(a);
+  (void) hipEventDestroy(b);
+  (void) hipFree(buf);
+  (void) hipFree(sink);
+  return 0;
+}
+
 extern "C" int vsa_measure_stream_read(uint64_t bytes, int device,
                                        double *gbps)
 {
