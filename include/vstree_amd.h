@@ -282,6 +282,19 @@ int vsa_findquerymatches(const vsa_index *index, const vsa_queries *queries,
                          uint64_t searchlength, vsa_result **result);
 
 /*
+  findsupermax (Vmengine/fsuper.c:142-165), vmatch -supermax -l L IDX:
+  supermaximal repeats of the index.  A match is (length, start1, start2, 0)
+  with start1 < start2, laid out like the self-index MUMs (dbstart = start1,
+  queryseq = start2 as an absolute position).  Order: the nodes of the
+  lcp-interval tree in suffix array order, the pairs of a node by first,
+  then second suffix -- the reference's order.  An index that holds queries
+  is the reference's error "supermaximal repeat search does not allow query
+  files in index" (Vmengine/fself.c:193-198).  Needs the bwt table.
+*/
+int vsa_findsupermaximalrepeats(const vsa_index *index, uint64_t searchlength,
+                                vsa_result **result);
+
+/*
   findmaximaluniquematches (Vmengine/fmumself.c:10-66): MUMs between the
   database and the query part of one index.  Reported like the reference's
   Outputfunction(outinfo, len, start1, start2): length, dbstart = start1,
@@ -336,6 +349,9 @@ int vsa_findmaximaluniquematches_cb(const vsa_index *index,
                                     uint64_t searchlength,
                                     vsa_processmatch processmatch,
                                     void *info);
+int vsa_findsupermaximalrepeats_cb(const vsa_index *index,
+                                   uint64_t searchlength,
+                                   vsa_processmatch processmatch, void *info);
 
 /* ---- synthetic inputs (bench.py, tests): SURVEY.md section 8d ---------- */
 

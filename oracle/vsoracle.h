@@ -136,6 +136,10 @@ int orc_findapproxcompletematches(const orc_index *idx, const uint8_t *qbuf,
                                   const uint64_t *qlen, uint64_t nq,
                                   int doedist, uint64_t distvalue,
                                   int percent, orc_matches *out, char *err);
+/* vmatch -supermax -l L IDX (oracle/vsself.c): Vmengine/fsuper.c:60-165.
+   length, dbstart = smaller start, queryseq = larger start, querystart 0. */
+int orc_findsupermax(const orc_index *idx, uint64_t searchlength,
+                     orc_matches *out, char *err);
 uint64_t orc_getoptsplit(int doedist, uint64_t spliterrorbound,
                          uint64_t numofchars, uint64_t textlen,
                          uint64_t patternlength, uint64_t threshold);

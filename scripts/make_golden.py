@@ -109,6 +109,8 @@ def main():
                 "ychrIII.fna"], wd)
     record(case, "mem300", ["-l", "300", "-q", "LargePat.test",
                             "ychrIII.fna"], wd)
+    # supermaximal repeats of the chromosome itself (Vmengine/fsuper.c)
+    record(case, "supermax30", ["-supermax", "-l", "30", "ychrIII.fna"], wd)
     shutil.rmtree(wd)
 
     # ---- 2. micro: multi-FASTA, wildcards, prefixlength 1 ----------------
@@ -138,6 +140,7 @@ def main():
                                        "q.fna", "db.fna"], wd)
         record(case, "mum%d" % L, ["-mum", "-l", str(L), "-q", "q.fna",
                                    "db.fna"], wd)
+    record(case, "supermax2", ["-supermax", "-l", "2", "db.fna"], wd)
     shutil.rmtree(wd)
 
     # ---- 3. Wildcards.fna of the reference's test data --------------------
@@ -180,6 +183,7 @@ def main():
     shutil.copy(wd + "/short.fna", GOLD + "/short.fna")
     record(case, "complete_short", ["-complete", "-q", "short.fna", dbf], wd)
     record(case, "mem8_short", ["-l", "8", "-q", "short.fna", dbf], wd)
+    record(case, "supermax12", ["-supermax", "-l", "12", dbf], wd)
     # queries inside the index (Mum.sh:35-61): vmatch -mum on db+query index
     manifest["grumbach_all"] = {"db": [dbf + ".gz"], "indexedquery":
                                 [qf + ".gz"], "runs": {}}
@@ -285,6 +289,7 @@ def main():
     record(case, "approx_e2p", ["-complete", "-e", "2p", "-q", "reads.fna",
                                 "db.fna"], wd, approx=True)
     record(case, "complete", ["-complete", "-q", "reads.fna", "db.fna"], wd)
+    record(case, "supermax20", ["-supermax", "-l", "20", "db.fna"], wd)
     shutil.rmtree(wd)
 
     np.savez_compressed(GOLD + "/expected.npz", **arrays)

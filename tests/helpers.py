@@ -56,12 +56,12 @@ def build_oracle():
     """Compile oracle/vsoracle.c if the .so is missing or stale."""
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f)
-            for f in ("vsoracle.c", "vsindex.c", "vsapprox.c",
+            for f in ("vsoracle.c", "vsindex.c", "vsapprox.c", "vsself.c",
                       "vsoracle_body.inc", "vsoracle.h")]
     if (not os.path.exists(so) or
             os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", srcs[0],
-                               srcs[1], srcs[2], "-lm", "-o", so])
+                               srcs[1], srcs[2], srcs[3], "-lm", "-o", so])
     return so
 
 
@@ -89,6 +89,9 @@ def oracle_lib():
             C.c_char_p]
         lib.orc_findapproxcompletematches.argtypes = common + [
             C.c_int, C.c_uint64, C.c_int, C.POINTER(OrcMatches), C.c_char_p]
+        lib.orc_findsupermax.argtypes = [
+            C.POINTER(OrcIndex), C.c_uint64, C.POINTER(OrcMatches),
+            C.c_char_p]
         lib.orc_getoptsplit.argtypes = [C.c_int] + [C.c_uint64] * 5
         lib.orc_getoptsplit.restype = C.c_uint64
         lib.orc_mumuniqueinquery.argtypes = [C.c_void_p, C.c_uint64,
@@ -248,6 +251,20 @@ def oracle_complete(index, queries, online=False):
         e = OracleError(err.value.decode())
         e.partial = res
         raise e
+    return res
+
+
+def oracle_supermax(index, searchlength):
+    """vmatch -supermax -l L IDX: (length, start1, start2, 0)"""
+    lib = oracle_lib()
+    out, err = OrcMatches(), C.create_string_buffer(512)
+    lib.orc_matches_init(C.byref(out))
+    oi = index.orc()
+    rc = lib.orc_findsupermax(C.byref(oi), int(searchlength), C.byref(out),
+                              err)
+    res = _take(out)
+    if rc != 0:
+        raise OracleError(err.value.decode())
     return res
 
 
@@ -619,6 +636,19 @@ def load_case(case):
         idx.numofdbsequences = idx.numofsequences
     _cases[case] = (idx, queries)
     return _cases[case]
+
+
+def repeats_as_ref(index, m):
+    """self matches (length, start1, start2) of an index without queries ->
+    the reference's output tuple"""
+    dt = np.dtype([("length", "<u8"), ("dbseq", "<u8"), ("dbrel", "<u8"),
+                   ("queryseq", "<u8"), ("querystart", "<u8")])
+    out = np.zeros(m.shape[0], dt)
+    s1, r1 = index.seq_rel(m["dbstart"])
+    s2, r2 = index.seq_rel(m["queryseq"])
+    out["length"], out["dbseq"], out["dbrel"] = m["length"], s1, r1
+    out["queryseq"], out["querystart"] = s2, r2
+    return out
 
 
 def selfmatches_as_ref(index, m):

@@ -34,6 +34,9 @@ def run_gpu(V, case, key, bits=64):
     if key.startswith("selfmum"):
         r = V.findmaximaluniquematches(gi, int(key[len("selfmum"):]))
         return H.selfmatches_as_ref(idx, r.fetch())
+    if key.startswith("supermax"):
+        r = V.findsupermaximalrepeats(gi, int(key[len("supermax"):]))
+        return H.repeats_as_ref(idx, r.fetch())
     gq = gpu_queries(V, q)
     if key.startswith("complete"):
         return H.matches_as_ref(idx, V.findcompletematches(gi, gq).fetch())
@@ -359,3 +362,39 @@ def test_reverse_complement_of_a_protein_batch_is_the_reference_error(V):
     with pytest.raises(V.VsaError) as ei:
         gpu_queries(V, q).reverse_complement()
     assert "reverse complement of 7 undefined" in str(ei.value)
+
+
+def test_supermaximal_repeats_on_a_repetitive_text(V):
+    """many nodes with more than two suffixes, wildcards and separators to
+    the left of repeat copies, a copy at the very start of the text"""
+    rng = np.random.default_rng(77)
+    unit = rng.integers(0, 4, 300).astype(np.uint8)
+    seqs = []
+    for s in range(3):
+        t = rng.integers(0, 4, 20000).astype(np.uint8)
+        for r in range(10):
+            p = int(rng.integers(0, 20000 - 300))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 4))):
+                u[int(rng.integers(0, 300))] = rng.integers(0, 4)
+            t[p:p + 300] = u
+        t[rng.random(20000) < 0.002] = H.WILDCARD
+        seqs.append(t)
+    seqs[0][:60] = unit[:60]
+    tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
+                          for s in seqs])[:-1].astype(np.uint8)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    for L in (8, 20, 60):
+        got = V.findsupermaximalrepeats(gi, L).fetch()
+        want = H.oracle_supermax(host, L)
+        assert len(want) > 0 and np.array_equal(got, want)
+
+
+def test_supermaximal_repeats_refuse_an_index_with_queries(V):
+    gi = gpu_index(V, "grumbach_all")
+    with pytest.raises(V.VsaError) as ei:
+        V.findsupermaximalrepeats(gi, 14)
+    assert "does not allow query files in index" in str(ei.value)

@@ -63,6 +63,14 @@ def test_sink_prints_what_vmatch_printed(case, key):
                       numofquerysequences=prj["numofquerysequences"],
                       totalquerylength=idx.n - idx.querysepposition - 1,
                       leastlength=int(key[len("selfmum"):]))
+    elif key.startswith("supermax"):
+        starts = np.concatenate(([0], idx.ssp + 1)).astype(np.uint64)
+        m = records(idx, exp)
+        m["queryseq"] = starts[exp["queryseq"].astype(np.int64)] + \
+            exp["querystart"]
+        m["querystart"] = 0
+        sink = V.Sink(V.SINK_SELF, idx.n, idx.ssp, 4,
+                      leastlength=int(key[len("supermax"):]))
     else:
         kind, least = kind_of(key)
         m = records(idx, exp)

@@ -139,6 +139,8 @@ def _load():
                                                  PROCESSMATCH, V]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
+        "vsa_findsupermaximalrepeats": (I, [V, U64, PP]),
+        "vsa_findsupermaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
         "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
         "vsa_findmaximaluniquematches_cb": (I, [V, U64, PROCESSMATCH, V]),
@@ -389,6 +391,14 @@ def findquerymatches(index, queries, searchlength, mum=False, cand=False):
     _check(lib.vsa_findquerymatches(index._h, queries._h, int(mum),
                                     int(cand), int(searchlength),
                                     C.byref(h)))
+    return Result(h)
+
+
+def findsupermaximalrepeats(index, searchlength):
+    """vmatch -supermax -l L IDX (Vmengine/fsuper.c:142)."""
+    h = C.c_void_p()
+    _check(lib.vsa_findsupermaximalrepeats(index._h, int(searchlength),
+                                           C.byref(h)))
     return Result(h)
 
 

@@ -2420,6 +2420,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
 }
 
 #include "approx_search.inc"
+#include "selfmatch_search.inc"
 
 } // namespace
 
@@ -2759,6 +2760,51 @@ extern "C" int vsa_mumuniqueinquery_range(void *device_candidates,
 {
   return mumfilter_entry(device_candidates, ncandidates, device,
                          carry_dbright, result);
+}
+
+extern "C" int vsa_findsupermaximalrepeats(const vsa_index *index,
+                                           uint64_t searchlength,
+                                           vsa_result **result)
+{
+  if (index == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findsupermaximalrepeats: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (index->hasindexedqueries)
+  {
+    // Vmengine/fself.c:193-198
+    VSA_ERROR("supermaximal repeat search does not allow query files in "
+              "index");
+    return -2;
+  }
+  if (index->n < 2)
+  {
+    // Vmengine/fself.c:246-250
+    VSA_ERROR("repeat search requires a sequence of length >= 2");
+    return -2;
+  }
+  if (index->bwt == nullptr)
+  {
+    VSA_ERROR("table bwt is not loaded");
+    return -3;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc = (index->isize == 4)
+                     ? run_supermax<uint32_t>(index, searchlength, res)
+                     : run_supermax<uint64_t>(index, searchlength, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
 }
 
 extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,
