@@ -140,6 +140,10 @@ int orc_findapproxcompletematches(const orc_index *idx, const uint8_t *qbuf,
    length, dbstart = smaller start, queryseq = larger start, querystart 0. */
 int orc_findsupermax(const orc_index *idx, uint64_t searchlength,
                      orc_matches *out, char *err);
+/* vmatch -l L IDX, maximal repeats (oracle/vsself.c):
+   Vmengine/vmatfind.c:330-541 in the reference's order. */
+int orc_findmaximalrepeats(const orc_index *idx, uint64_t searchlength,
+                           orc_matches *out, char *err);
 uint64_t orc_getoptsplit(int doedist, uint64_t spliterrorbound,
                          uint64_t numofchars, uint64_t textlen,
                          uint64_t patternlength, uint64_t threshold);

@@ -141,3 +141,277 @@ int orc_findsupermax(const orc_index *ix, uint64_t searchlength,
   }
   return 0;
 }
+
+/*
+  Maximal repeats, vmatch -l L IDX:
+    vmatmaxoutgeneric (VMATMAXOUT)   Vmengine/vmatfind.c:487-541
+    processleafedge                  Vmengine/vmatfind.c:330-400
+    processbranch                    Vmengine/vmatfind.c:413-473
+    cartproduct1/2, addtoposlist     Vmengine/vmatfind.c:170-291
+    the traversal                    include/vdfstrav.c:247-420
+  A node of the lcp-interval tree of depth >= L keeps the start positions of
+  the suffixes below it in one list per left character (regular symbols) and
+  one list for the others (special symbols, start of the text).  Whenever a
+  child -- a leaf or a finished subtree -- is attached to its father, every
+  pair (position already at the father, position of the child) with
+  different or non-regular left characters is a maximal repeat of length
+  depth(father), in the order of the nested loops below.  This is a direct
+  simulation with explicit lists (the reference keeps them in shared stacks,
+  which is the same thing).
+*/
+
+typedef struct
+{
+  uint64_t *v;
+  uint64_t n, cap;
+} Vec;
+
+static void vecpush(Vec *a, uint64_t x)
+{
+  if (a->n == a->cap)
+  {
+    a->cap = a->cap ? 2 * a->cap : 8;
+    a->v = (uint64_t *) realloc(a->v, a->cap * sizeof(uint64_t));
+    if (a->v == NULL)
+    {
+      fprintf(stderr, "oracle: out of memory\n");
+      exit(EXIT_FAILURE);
+    }
+  }
+  a->v[a->n++] = x;
+}
+
+static void vecappend(Vec *a, const Vec *b)
+{
+  uint64_t i;
+  for (i = 0; i < b->n; i++)
+  {
+    vecpush(a, b->v[i]);
+  }
+}
+
+typedef struct
+{
+  uint64_t depth;
+  int lastisleafedge;
+  Vec *cls; /* numofchars lists */
+  Vec uniq;
+} Rnode;
+
+typedef struct
+{
+  const orc_index *ix;
+  uint64_t searchlength, depth;
+  uint32_t nc;
+  orc_matches *out;
+} Rstate;
+
+static void routput(Rstate *st, uint64_t i, uint64_t j)
+{
+  /* processexactselfmatch: ACCEPTMATCH, fself.c:21-38 */
+  orc_push_match(st->out, st->depth, i < j ? i : j, i < j ? j : i, 0);
+}
+
+static void rleafedge(Rstate *st, int firstsucc, Rnode *father,
+                      uint32_t leftchar, uint64_t leaf)
+{
+  uint32_t base;
+  uint64_t k;
+
+  if (father->depth < st->searchlength)
+  {
+    return;
+  }
+  st->depth = father->depth;
+  if (firstsucc)
+  {
+    for (base = 0; base < st->nc; base++)
+    {
+      father->cls[base].n = 0;
+    }
+    father->uniq.n = 0;
+  } else
+  {
+    for (base = 0; base < st->nc; base++)
+    {
+      if (base != leftchar)
+      {
+        for (k = 0; k < father->cls[base].n; k++)
+        {
+          routput(st, leaf, father->cls[base].v[k]);
+        }
+      }
+    }
+    for (k = 0; k < father->uniq.n; k++)
+    {
+      routput(st, leaf, father->uniq.v[k]);
+    }
+  }
+  if (leftchar >= st->nc)
+  {
+    vecpush(&father->uniq, leaf);
+  } else
+  {
+    vecpush(&father->cls[leftchar], leaf);
+  }
+}
+
+static void rbranch(Rstate *st, int firstsucc, Rnode *father, Rnode *son)
+{
+  uint32_t chf, chs;
+  uint64_t a, b;
+
+  if (father->depth < st->searchlength || firstsucc)
+  {
+    return; /* first child: the father took over the son's slot and lists */
+  }
+  st->depth = father->depth;
+  for (chf = 0; chf < st->nc; chf++)
+  {
+    for (chs = 0; chs < st->nc; chs++)
+    {
+      if (chs != chf)
+      {
+        for (a = 0; a < father->cls[chf].n; a++)
+        {
+          for (b = 0; b < son->cls[chs].n; b++)
+          {
+            routput(st, father->cls[chf].v[a], son->cls[chs].v[b]);
+          }
+        }
+      }
+    }
+    for (b = 0; b < son->uniq.n; b++)
+    {
+      for (a = 0; a < father->cls[chf].n; a++)
+      {
+        routput(st, son->uniq.v[b], father->cls[chf].v[a]);
+      }
+    }
+  }
+  for (a = 0; a < father->uniq.n; a++)
+  {
+    for (chs = 0; chs < st->nc; chs++)
+    {
+      for (b = 0; b < son->cls[chs].n; b++)
+      {
+        routput(st, father->uniq.v[a], son->cls[chs].v[b]);
+      }
+    }
+    for (b = 0; b < son->uniq.n; b++)
+    {
+      routput(st, father->uniq.v[a], son->uniq.v[b]);
+    }
+  }
+  for (chs = 0; chs < st->nc; chs++)
+  {
+    vecappend(&father->cls[chs], &son->cls[chs]);
+  }
+  vecappend(&father->uniq, &son->uniq);
+}
+
+int orc_findmaximalrepeats(const orc_index *ix, uint64_t searchlength,
+                           orc_matches *out, char *err)
+{
+  Rnode *stack = NULL;
+  uint64_t allocated = 0, top = 0, c, k; /* top = number of nodes */
+  Rstate st;
+  int firstrootedge = 1;
+
+  if (ix->bwt == NULL)
+  {
+    snprintf(err, 256, "table bwt is not loaded");
+    return -1;
+  }
+  if (ix->hasqueries)
+  {
+    snprintf(err, 256, "repeats of an index with queries are not covered "
+             "by the oracle");
+    return -4;
+  }
+  if (ix->n < 2)
+  {
+    snprintf(err, 256, "repeat search requires a sequence of length >= 2");
+    return -1;
+  }
+  st.ix = ix;
+  st.searchlength = searchlength;
+  st.depth = 0;
+  st.nc = ix->numofchars;
+  st.out = out;
+#define NEEDSLOT(I)                                                           \
+  while ((I) >= allocated)                                                    \
+  {                                                                           \
+    const uint64_t na = allocated ? 2 * allocated : 64;                       \
+    stack = (Rnode *) realloc(stack, na * sizeof(Rnode));                     \
+    for (k = allocated; k < na; k++)                                          \
+    {                                                                         \
+      memset(stack + k, 0, sizeof(Rnode));                                    \
+      stack[k].cls = (Vec *) calloc(st.nc, sizeof(Vec));                      \
+    }                                                                         \
+    allocated = na;                                                           \
+  }
+  NEEDSLOT(1);
+  stack[0].depth = 0;
+  stack[0].lastisleafedge = 1;
+  top = 1;
+  for (c = 0; c + 1 <= ix->n; c++) /* leaves 0 .. n-1; lcp[c+1] follows c */
+  {
+    const uint64_t currentlcp = lcpat(ix, c + 1), leaf = sufat(ix, c);
+    const uint32_t leftchar = (leaf == 0) ? st.nc + 1 : ix->bwt[c];
+
+    while (currentlcp < stack[top - 1].depth)
+    {
+      if (stack[top - 1].lastisleafedge)
+      {
+        rleafedge(&st, 0, stack + top - 1, leftchar, leaf);
+      } else
+      {
+        rbranch(&st, 0, stack + top - 1, stack + top);
+      }
+      top--;
+    }
+    if (currentlcp == stack[top - 1].depth)
+    {
+      int firstedge = 0;
+      if (firstrootedge && stack[top - 1].depth == 0)
+      {
+        firstedge = 1;
+        firstrootedge = 0;
+      }
+      if (stack[top - 1].lastisleafedge)
+      {
+        rleafedge(&st, firstedge, stack + top - 1, leftchar, leaf);
+      } else
+      {
+        rbranch(&st, firstedge, stack + top - 1, stack + top);
+        stack[top - 1].lastisleafedge = 1;
+      }
+    } else
+    {
+      NEEDSLOT(top + 1);
+      stack[top].depth = currentlcp;
+      stack[top].lastisleafedge = 1;
+      top++;
+      if (stack[top - 2].lastisleafedge)
+      {
+        rleafedge(&st, 1, stack + top - 1, leftchar, leaf);
+        stack[top - 2].lastisleafedge = 0;
+      } /* else: the slot still holds the lists of the son just finished */
+    }
+  }
+  /* the last leaf n hangs below the root (lcp[n] = 0): nothing to report */
+  for (k = 0; k < allocated; k++)
+  {
+    uint32_t b;
+    for (b = 0; b < st.nc; b++)
+    {
+      free(stack[k].cls[b].v);
+    }
+    free(stack[k].cls);
+    free(stack[k].uniq.v);
+  }
+  free(stack);
+#undef NEEDSLOT
+  return 0;
+}

@@ -111,6 +111,8 @@ def main():
                             "ychrIII.fna"], wd)
     # supermaximal repeats of the chromosome itself (Vmengine/fsuper.c)
     record(case, "supermax30", ["-supermax", "-l", "30", "ychrIII.fna"], wd)
+    # maximal repeats (Vmengine/vmatfind.c), the default task of vmatch
+    record(case, "repeats40", ["-l", "40", "ychrIII.fna"], wd)
     shutil.rmtree(wd)
 
     # ---- 2. micro: multi-FASTA, wildcards, prefixlength 1 ----------------
@@ -141,6 +143,7 @@ def main():
         record(case, "mum%d" % L, ["-mum", "-l", str(L), "-q", "q.fna",
                                    "db.fna"], wd)
     record(case, "supermax2", ["-supermax", "-l", "2", "db.fna"], wd)
+    record(case, "repeats2", ["-l", "2", "db.fna"], wd)
     shutil.rmtree(wd)
 
     # ---- 3. Wildcards.fna of the reference's test data --------------------
@@ -184,6 +187,7 @@ def main():
     record(case, "complete_short", ["-complete", "-q", "short.fna", dbf], wd)
     record(case, "mem8_short", ["-l", "8", "-q", "short.fna", dbf], wd)
     record(case, "supermax12", ["-supermax", "-l", "12", dbf], wd)
+    record(case, "repeats12", ["-l", "12", dbf], wd)
     # queries inside the index (Mum.sh:35-61): vmatch -mum on db+query index
     manifest["grumbach_all"] = {"db": [dbf + ".gz"], "indexedquery":
                                 [qf + ".gz"], "runs": {}}
@@ -290,6 +294,7 @@ def main():
                                 "db.fna"], wd, approx=True)
     record(case, "complete", ["-complete", "-q", "reads.fna", "db.fna"], wd)
     record(case, "supermax20", ["-supermax", "-l", "20", "db.fna"], wd)
+    record(case, "repeats25", ["-l", "25", "db.fna"], wd)
     shutil.rmtree(wd)
 
     np.savez_compressed(GOLD + "/expected.npz", **arrays)

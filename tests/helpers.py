@@ -92,6 +92,9 @@ def oracle_lib():
         lib.orc_findsupermax.argtypes = [
             C.POINTER(OrcIndex), C.c_uint64, C.POINTER(OrcMatches),
             C.c_char_p]
+        lib.orc_findmaximalrepeats.argtypes = [
+            C.POINTER(OrcIndex), C.c_uint64, C.POINTER(OrcMatches),
+            C.c_char_p]
         lib.orc_getoptsplit.argtypes = [C.c_int] + [C.c_uint64] * 5
         lib.orc_getoptsplit.restype = C.c_uint64
         lib.orc_mumuniqueinquery.argtypes = [C.c_void_p, C.c_uint64,
@@ -262,6 +265,20 @@ def oracle_supermax(index, searchlength):
     oi = index.orc()
     rc = lib.orc_findsupermax(C.byref(oi), int(searchlength), C.byref(out),
                               err)
+    res = _take(out)
+    if rc != 0:
+        raise OracleError(err.value.decode())
+    return res
+
+
+def oracle_repeats(index, searchlength):
+    """vmatch -l L IDX (maximal repeats): (length, start1, start2, 0)"""
+    lib = oracle_lib()
+    out, err = OrcMatches(), C.create_string_buffer(512)
+    lib.orc_matches_init(C.byref(out))
+    oi = index.orc()
+    rc = lib.orc_findmaximalrepeats(C.byref(oi), int(searchlength),
+                                    C.byref(out), err)
     res = _take(out)
     if rc != 0:
         raise OracleError(err.value.decode())

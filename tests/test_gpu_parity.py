@@ -56,7 +56,8 @@ def run_gpu(V, case, key, bits=64):
 # other MEM lists as sets; complete / MUM / candidate lists always in order
 CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
          if not k.endswith("_short") and "strands" not in M[c]["runs"][k]
-         and not k.startswith("approx_")]   # those: tests/test_gpu_approx.py
+         and not k.startswith("approx_")    # those: tests/test_gpu_approx.py
+         and not k.startswith("repeats")]
 
 
 @pytest.mark.parametrize("case,key", CASES)

@@ -30,6 +30,9 @@ def run_oracle(case, key):
     if key.startswith("selfmum"):
         L = int(key[len("selfmum"):])
         return H.selfmatches_as_ref(idx, H.oracle_selfmum(idx, L)), None
+    if key.startswith("repeats"):
+        L = int(key[len("repeats"):])
+        return H.repeats_as_ref(idx, H.oracle_repeats(idx, L)), None
     if key.startswith("supermax"):
         L = int(key[len("supermax"):])
         return H.repeats_as_ref(idx, H.oracle_supermax(idx, L)), None

@@ -63,14 +63,15 @@ def test_sink_prints_what_vmatch_printed(case, key):
                       numofquerysequences=prj["numofquerysequences"],
                       totalquerylength=idx.n - idx.querysepposition - 1,
                       leastlength=int(key[len("selfmum"):]))
-    elif key.startswith("supermax"):
+    elif key.startswith("supermax") or key.startswith("repeats"):
         starts = np.concatenate(([0], idx.ssp + 1)).astype(np.uint64)
         m = records(idx, exp)
         m["queryseq"] = starts[exp["queryseq"].astype(np.int64)] + \
             exp["querystart"]
         m["querystart"] = 0
         sink = V.Sink(V.SINK_SELF, idx.n, idx.ssp, 4,
-                      leastlength=int(key[len("supermax"):]))
+                      leastlength=int("".join(
+                          ch for ch in key if ch.isdigit())))
     else:
         kind, least = kind_of(key)
         m = records(idx, exp)
