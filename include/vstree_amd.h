@@ -282,6 +282,23 @@ int vsa_findquerymatches(const vsa_index *index, const vsa_queries *queries,
                          uint64_t searchlength, vsa_result **result);
 
 /*
+  findselfmatches with vmatmaxoutgeneric (Vmengine/fself.c:203-300,
+  Vmengine/vmatfind.c:487-541), vmatch -l L IDX: maximal repeats of the
+  index -- all pairs of positions whose common prefix has length >= L, cannot
+  be extended to the right (its length is the reported one) and is left
+  maximal (different left characters, or a special symbol / the start of the
+  text on one side).  A match is (length, start1, start2, 0) with start1 <
+  start2.  Order: the reference's -- attachments of children to their fathers
+  in the order of its bottom-up traversal, the pairs of one attachment in the
+  order of the nested loops of processbranch (vmatfind.c:433-469).  With
+  queries inside the index only pairs of a database and a query position are
+  reported (ACCEPTMATCH, fself.c:29-37).  Needs the bwt table.
+  VSA_NOT_COVERED for alphabets of more than 32 symbols.
+*/
+int vsa_findmaximalrepeats(const vsa_index *index, uint64_t searchlength,
+                           vsa_result **result);
+
+/*
   findsupermax (Vmengine/fsuper.c:142-165), vmatch -supermax -l L IDX:
   supermaximal repeats of the index.  A match is (length, start1, start2, 0)
   with start1 < start2, laid out like the self-index MUMs (dbstart = start1,
@@ -352,6 +369,8 @@ int vsa_findmaximaluniquematches_cb(const vsa_index *index,
 int vsa_findsupermaximalrepeats_cb(const vsa_index *index,
                                    uint64_t searchlength,
                                    vsa_processmatch processmatch, void *info);
+int vsa_findmaximalrepeats_cb(const vsa_index *index, uint64_t searchlength,
+                              vsa_processmatch processmatch, void *info);
 
 /* ---- synthetic inputs (bench.py, tests): SURVEY.md section 8d ---------- */
 

@@ -209,7 +209,14 @@ typedef struct
 static void routput(Rstate *st, uint64_t i, uint64_t j)
 {
   /* processexactselfmatch: ACCEPTMATCH, fself.c:21-38 */
-  orc_push_match(st->out, st->depth, i < j ? i : j, i < j ? j : i, 0);
+  const uint64_t start1 = i < j ? i : j, start2 = i < j ? j : i;
+
+  if (st->ix->hasqueries && (start1 >= st->ix->querysepposition ||
+                             start2 <= st->ix->querysepposition))
+  {
+    return; /* only database against query */
+  }
+  orc_push_match(st->out, st->depth, start1, start2, 0);
 }
 
 static void rleafedge(Rstate *st, int firstsucc, Rnode *father,
@@ -322,12 +329,6 @@ int orc_findmaximalrepeats(const orc_index *ix, uint64_t searchlength,
   {
     snprintf(err, 256, "table bwt is not loaded");
     return -1;
-  }
-  if (ix->hasqueries)
-  {
-    snprintf(err, 256, "repeats of an index with queries are not covered "
-             "by the oracle");
-    return -4;
   }
   if (ix->n < 2)
   {

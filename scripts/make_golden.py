@@ -195,6 +195,8 @@ def main():
         wd, "all", ["-indexname", "all", "-db", dbf, "-q", qf, "-dna", "-pl",
                     "-allout"])
     record("grumbach_all", "selfmum14", ["-mum", "-l", "14", "all"], wd)
+    # maximal repeats between database and query of the same index
+    record("grumbach_all", "repeats14", ["-l", "14", "all"], wd)
     shutil.rmtree(wd)
 
     # ---- 5. C1: synthetic 1 Mbp genome, 10 k x 100 bp queries -------------

@@ -37,6 +37,10 @@ def run_gpu(V, case, key, bits=64):
     if key.startswith("supermax"):
         r = V.findsupermaximalrepeats(gi, int(key[len("supermax"):]))
         return H.repeats_as_ref(idx, r.fetch())
+    if key.startswith("repeats"):
+        r = V.findmaximalrepeats(gi, int(key[len("repeats"):]))
+        conv = H.selfmatches_as_ref if idx.hasqueries else H.repeats_as_ref
+        return conv(idx, r.fetch())
     gq = gpu_queries(V, q)
     if key.startswith("complete"):
         return H.matches_as_ref(idx, V.findcompletematches(gi, gq).fetch())
@@ -56,8 +60,7 @@ def run_gpu(V, case, key, bits=64):
 # other MEM lists as sets; complete / MUM / candidate lists always in order
 CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
          if not k.endswith("_short") and "strands" not in M[c]["runs"][k]
-         and not k.startswith("approx_")    # those: tests/test_gpu_approx.py
-         and not k.startswith("repeats")]
+         and not k.startswith("approx_")]   # those: tests/test_gpu_approx.py
 
 
 @pytest.mark.parametrize("case,key", CASES)
@@ -392,6 +395,36 @@ def test_supermaximal_repeats_on_a_repetitive_text(V):
         got = V.findsupermaximalrepeats(gi, L).fetch()
         want = H.oracle_supermax(host, L)
         assert len(want) > 0 and np.array_equal(got, want)
+
+
+def test_maximal_repeats_on_a_repetitive_text(V):
+    """deep nodes with many children and grandchildren: the order of the
+    reference's bottom-up traversal must come out of the slot arithmetic"""
+    rng = np.random.default_rng(99)
+    unit = rng.integers(0, 4, 200).astype(np.uint8)
+    seqs = []
+    for s in range(3):
+        t = rng.integers(0, 4, 15000).astype(np.uint8)
+        for r in range(12):
+            p = int(rng.integers(0, 15000 - 200))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 5))):
+                u[int(rng.integers(0, 200))] = rng.integers(0, 4)
+            t[p:p + 200] = u
+        t[3000:3300] = np.tile(np.array([0, 1, 0, 2], np.uint8), 75)
+        t[rng.random(15000) < 0.002] = H.WILDCARD
+        seqs.append(t)
+    seqs[0][:50] = unit[:50]
+    tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
+                          for s in seqs])[:-1].astype(np.uint8)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    for L in (10, 25, 80):
+        got = V.findmaximalrepeats(gi, L).fetch()
+        want = H.oracle_repeats(host, L)
+        assert len(want) > 100 and np.array_equal(got, want)
 
 
 def test_supermaximal_repeats_refuse_an_index_with_queries(V):

@@ -32,7 +32,8 @@ def run_oracle(case, key):
         return H.selfmatches_as_ref(idx, H.oracle_selfmum(idx, L)), None
     if key.startswith("repeats"):
         L = int(key[len("repeats"):])
-        return H.repeats_as_ref(idx, H.oracle_repeats(idx, L)), None
+        conv = H.selfmatches_as_ref if idx.hasqueries else H.repeats_as_ref
+        return conv(idx, H.oracle_repeats(idx, L)), None
     if key.startswith("supermax"):
         L = int(key[len("supermax"):])
         return H.repeats_as_ref(idx, H.oracle_supermax(idx, L)), None

@@ -49,7 +49,8 @@ def test_sink_prints_what_vmatch_printed(case, key):
     idx, q = H.load_case(case)
     run = M[case]["runs"][key]
     exp = H.expected(case, key)
-    if key.startswith("selfmum"):
+    if key.startswith("selfmum") or (key.startswith("repeats") and
+                                     idx.hasqueries):
         # records are (length, start1, start2): rebuild start2 from the
         # query-side sequence number the reference printed
         prj = M[case]["index"]["prj"]
@@ -62,7 +63,8 @@ def test_sink_prints_what_vmatch_printed(case, key):
         sink = V.Sink(V.SINK_SELF, idx.n, idx.ssp, 4,
                       numofquerysequences=prj["numofquerysequences"],
                       totalquerylength=idx.n - idx.querysepposition - 1,
-                      leastlength=int(key[len("selfmum"):]))
+                      leastlength=int("".join(
+                          ch for ch in key if ch.isdigit())))
     elif key.startswith("supermax") or key.startswith("repeats"):
         starts = np.concatenate(([0], idx.ssp + 1)).astype(np.uint64)
         m = records(idx, exp)

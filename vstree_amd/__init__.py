@@ -139,6 +139,8 @@ def _load():
                                                  PROCESSMATCH, V]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
+        "vsa_findmaximalrepeats": (I, [V, U64, PP]),
+        "vsa_findmaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findsupermaximalrepeats": (I, [V, U64, PP]),
         "vsa_findsupermaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
@@ -391,6 +393,14 @@ def findquerymatches(index, queries, searchlength, mum=False, cand=False):
     _check(lib.vsa_findquerymatches(index._h, queries._h, int(mum),
                                     int(cand), int(searchlength),
                                     C.byref(h)))
+    return Result(h)
+
+
+def findmaximalrepeats(index, searchlength):
+    """vmatch -l L IDX (Vmengine/vmatfind.c:487), the reference's order."""
+    h = C.c_void_p()
+    _check(lib.vsa_findmaximalrepeats(index._h, int(searchlength),
+                                      C.byref(h)))
     return Result(h)
 
 

@@ -110,3 +110,12 @@ int vsa_findsupermaximalrepeats_cb(const vsa_index *index,
 
   return replay(result, rc, processmatch, info);
 }
+
+int vsa_findmaximalrepeats_cb(const vsa_index *index, uint64_t searchlength,
+                              vsa_processmatch processmatch, void *info)
+{
+  vsa_result *result = NULL;
+  int rc = vsa_findmaximalrepeats(index, searchlength, &result);
+
+  return replay(result, rc, processmatch, info);
+}

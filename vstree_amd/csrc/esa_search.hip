@@ -2762,6 +2762,55 @@ extern "C" int vsa_mumuniqueinquery_range(void *device_candidates,
                          carry_dbright, result);
 }
 
+extern "C" int vsa_findmaximalrepeats(const vsa_index *index,
+                                      uint64_t searchlength,
+                                      vsa_result **result)
+{
+  if (index == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findmaximalrepeats: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (index->n < 2)
+  {
+    // Vmengine/fself.c:246-250
+    VSA_ERROR("repeat search requires a sequence of length >= 2");
+    return -2;
+  }
+  if (index->bwt == nullptr)
+  {
+    VSA_ERROR("table bwt is not loaded");
+    return -3;
+  }
+  if (index->numofchars > VSA_REP_MAXC)
+  {
+    VSA_ERROR("maximal repeats on alphabets of %lu symbols are not covered "
+              "by the GPU engine", (unsigned long) index->numofchars);
+    return VSA_NOT_COVERED;
+  }
+  if (searchlength == 0)
+  {
+    VSA_ERROR("maximal repeats need a length of at least 1");
+    return -2;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc = (index->isize == 4)
+                     ? run_repeats<uint32_t>(index, searchlength, res)
+                     : run_repeats<uint64_t>(index, searchlength, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
+}
+
 extern "C" int vsa_findsupermaximalrepeats(const vsa_index *index,
                                            uint64_t searchlength,
                                            vsa_result **result)
