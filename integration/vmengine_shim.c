@@ -409,3 +409,92 @@ Sint __wrap_findmaximaluniquematches(Virtualtree *virtualtree,
   }
   return 0;
 }
+
+/* ---- vmatch -l L IDX (maximal repeats) and vmatch -supermax -l L IDX ------ */
+
+/* the traversals findselfmatches dispatches to (Vmengine/fself.c:215-222):
+   findsupermax (fsuper.c:142) and, behind vmatmaxoutgeneric
+   (Vmengine/vmatgen.c), the instance of vmatfind.c for the alphabet size */
+Sint __real_findsupermax(Virtualtree *, Uint, Uint, void *, void *,
+                         Outputfunction);
+Sint __real_vmatmaxout4(Virtualtree *, Uint, Uint, void *, void *,
+                        Outputfunction);
+Sint __real_vmatmaxout12(Virtualtree *, Uint, Uint, void *, void *,
+                         Outputfunction);
+Sint __real_vmatmaxout21(Virtualtree *, Uint, Uint, void *, void *,
+                         Outputfunction);
+Sint __real_vmatmaxout31(Virtualtree *, Uint, Uint, void *, void *,
+                         Outputfunction);
+
+typedef Sint (*Selftraversal)(Virtualtree *, Uint, Uint, void *, void *,
+                              Outputfunction);
+
+static Sint gpuselfmatches(int supermax, Selftraversal real,
+                           Virtualtree *virtualtree, Uint numberofprocessors,
+                           Uint searchlength, void *repeatgapspec,
+                           void *outinfo, Outputfunction output)
+{
+  vsa_index *index;
+  Selfsink s;
+  int rc;
+
+  if (!usegpu() || virtualtree->suftab == NULL ||
+      virtualtree->lcptab == NULL || virtualtree->bwttab == NULL ||
+      (supermax && HASINDEXEDQUERIES(&virtualtree->multiseq)))
+  {
+    return real(virtualtree, numberofprocessors, searchlength, repeatgapspec,
+                outinfo, output);
+  }
+  if (gpuindexowner == virtualtree && gpuindex != NULL)
+  {
+    vsa_index_close(gpuindex); /* make sure the cached copy carries bwt */
+    gpuindex = NULL;
+  }
+  if (getgpuindex(virtualtree, 1, &index) != 0)
+  {
+    return (Sint) -3;
+  }
+  s.outinfo = outinfo;
+  s.output = output;
+  rc = supermax
+           ? vsa_findsupermaximalrepeats_cb(index, searchlength, selfsink, &s)
+           : vsa_findmaximalrepeats_cb(index, searchlength, selfsink, &s);
+  if (rc == VSA_NOT_COVERED)
+  {
+    return real(virtualtree, numberofprocessors, searchlength, repeatgapspec,
+                outinfo, output);
+  }
+  if (rc != 0)
+  {
+    if (rc != -1)
+    {
+      (void) gpufail();
+    }
+    return (Sint) -3;
+  }
+  return 0;
+}
+
+Sint __wrap_findsupermax(Virtualtree *virtualtree, Uint numberofprocessors,
+                         Uint searchlength, void *repeatgapspec,
+                         void *outinfo, Outputfunction output)
+{
+  return gpuselfmatches(1, __real_findsupermax, virtualtree,
+                        numberofprocessors, searchlength, repeatgapspec,
+                        outinfo, output);
+}
+
+#define WRAPMAXOUT(I)                                                         \
+  Sint __wrap_vmatmaxout##I(Virtualtree *virtualtree,                         \
+                            Uint numberofprocessors, Uint searchlength,       \
+                            void *repeatgapspec, void *outinfo,               \
+                            Outputfunction output)                            \
+  {                                                                           \
+    return gpuselfmatches(0, __real_vmatmaxout##I, virtualtree,               \
+                          numberofprocessors, searchlength, repeatgapspec,    \
+                          outinfo, output);                                   \
+  }
+WRAPMAXOUT(4)
+WRAPMAXOUT(12)
+WRAPMAXOUT(21)
+WRAPMAXOUT(31)
