@@ -237,8 +237,11 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
               t->integersize);
     return -2;
   }
-  if (t->tis == nullptr || t->suf == nullptr || t->lcp == nullptr ||
-      (t->largelcpvalues > 0 && t->llv == nullptr))
+  // tis may be missing together with bck: vmatch maps neither for the scans
+  // over the index itself (-supermax, repeats: Vmatch/mapdemand.c:100-210);
+  // every search that reads the text needs bck as well and checks for it
+  if ((t->tis == nullptr && t->bck != nullptr) || t->suf == nullptr ||
+      t->lcp == nullptr || (t->largelcpvalues > 0 && t->llv == nullptr))
   {
     VSA_ERROR("tables tis, suf, lcp (and llv) are required");
     return -3;
@@ -270,7 +273,7 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
     vsa_index_close(ix);
     return code;
   };
-  if (n > 0 &&
+  if (n > 0 && t->tis != nullptr &&
       hipMemcpyAsync(ix->tis_alloc + VSA_TIS_FRONTPAD, t->tis, n,
                      hipMemcpyHostToDevice, s) != hipSuccess)
   {
