@@ -72,6 +72,18 @@ static int usegpu(void)
   return e == NULL || strcmp(e, "0") != 0;
 }
 
+/* VMATCH_GPU_TRACE=1: one line on stderr per engine call that ran on the
+   GPU (tests/test_gpu_dropin.py uses it to make sure that a passing
+   comparison is not the CPU fallback in disguise) */
+static void trace(const char *what)
+{
+  const char *e = getenv("VMATCH_GPU_TRACE");
+  if (e != NULL && strcmp(e, "0") != 0)
+  {
+    fprintf(stderr, "vstree_amd: %s on the GPU\n", what);
+  }
+}
+
 static int gpufail(void)
 {
   ERROR1("%s", vsa_messagespace());
@@ -275,6 +287,7 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
     rc = vsa_findcompletematches_cb(index, queries, completesink,
                                     &matchstate);
   }
+  trace(approx ? "approximate complete matches" : "complete matches");
   vsa_queries_free(queries);
   if (rc != 0)
   {
@@ -342,6 +355,7 @@ Sint __wrap_findquerymatches(Virtualtree *virtualtree,
                                domaximaluniquematchcandidates ? 1 : 0,
                                matchparam->seedlength, querysink,
                                &matchstate);
+  trace("query matches");
   vsa_queries_free(queries);
   if (rc != 0)
   {
@@ -399,6 +413,7 @@ Sint __wrap_findmaximaluniquematches(Virtualtree *virtualtree,
   s.outinfo = outinfo;
   s.output = output;
   rc = vsa_findmaximaluniquematches_cb(index, searchlength, selfsink, &s);
+  trace("maximal unique matches of the index");
   if (rc != 0)
   {
     if (rc != -1)
@@ -464,6 +479,7 @@ static Sint gpuselfmatches(int supermax, Selftraversal real,
     return real(virtualtree, numberofprocessors, searchlength, repeatgapspec,
                 outinfo, output);
   }
+  trace(supermax ? "supermaximal repeats" : "maximal repeats");
   if (rc != 0)
   {
     if (rc != -1)

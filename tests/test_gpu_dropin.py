@@ -77,8 +77,13 @@ def test_vmatch_with_gpu_engine_prints_reference_output(case, tmp_path):
     stage(case, wd)
     H.run_mkvtree_ref(MKV[case] + ["-dna", "-pl", "-allout"], wd)
     for key, run in sorted(M[case]["runs"].items()):
-        rc, lines, err = run_gpu_vmatch(run["args"], wd)
+        rc, lines, err = run_gpu_vmatch(run["args"], wd,
+                                        {"VMATCH_GPU_TRACE": "1"})
         assert (rc != 0) == (run["rc"] != 0), (key, err)
+        # the engine call really ran on the GPU (Hamming distance with
+        # wildcards in the reads is the one run the engine declines)
+        if not (case == "c5" and key == "approx_h2"):
+            assert "on the GPU" in err, (case, key, err)
         if run["rc"] != 0:
             # same message as the reference, after the same matches
             assert run["stderr"].split(": ", 1)[1] in err
