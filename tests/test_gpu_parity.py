@@ -432,3 +432,21 @@ def test_supermaximal_repeats_refuse_an_index_with_queries(V):
     with pytest.raises(V.VsaError) as ei:
         V.findsupermaximalrepeats(gi, 14)
     assert "does not allow query files in index" in str(ei.value)
+
+
+def test_empty_results_leave_no_error_behind(V):
+    """a call that finds nothing (and so never starts its kernel timer) must
+    not poison the next call through the runtime's sticky last error"""
+    g = V.synth_genome(50000)
+    gi = V.Index.build(g, 4, 0)
+    assert V.findmaximalrepeats(gi, 10 ** 6).count == 0
+    assert V.findsupermaximalrepeats(gi, 10 ** 6).count == 0
+    assert V.findmaximalrepeats(gi, 10 ** 6).count == 0
+    empty = V.Queries.from_host(np.zeros(0, np.uint8), np.zeros(0, np.uint64),
+                                np.zeros(0, np.uint64))
+    assert V.findquerymatches(gi, empty, 20, mum=True).count == 0
+    assert V.findapproxcompletematches(gi, empty, True, 2).count == 0
+    assert V.findsupermaximalrepeats(gi, 12).count >= 0
+    tiny = V.Index.build(np.array([0, 1], np.uint8), 4, 1)
+    assert V.findmaximalrepeats(tiny, 1).count == 0
+    assert V.findsupermaximalrepeats(tiny, 1).count == 0

@@ -1435,6 +1435,7 @@ struct Timer
 {
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t s;
+  bool started = false, stopped = false;
   explicit Timer(hipStream_t stream) : s(stream)
   {
     (void) hipEventCreate(&a);
@@ -1447,16 +1448,23 @@ struct Timer
   }
   void start()
   {
-    (void) hipEventRecord(a, s);
+    started = hipEventRecord(a, s) == hipSuccess;
   }
   void stop()
   {
-    (void) hipEventRecord(b, s);
+    stopped = hipEventRecord(b, s) == hipSuccess;
   }
   double ms() // after the stream has been synchronised
   {
+    // a timer that never ran must not leave an error behind: the runtime
+    // keeps the last error, and the next library call would report it
     float f = 0;
-    (void) hipEventElapsedTime(&f, a, b);
+    if (!started || !stopped ||
+        hipEventElapsedTime(&f, a, b) != hipSuccess)
+    {
+      (void) hipGetLastError();
+      return 0.0;
+    }
     return (double) f;
   }
 };
