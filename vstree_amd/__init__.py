@@ -268,7 +268,7 @@ class Index:
         return out
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:   # None at interpreter shutdown
             lib.vsa_index_close(self._h)
             self._h = None
 
@@ -311,7 +311,7 @@ class Queries:
         return Queries(h, self.nq)
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:
             lib.vsa_queries_free(self._h)
             self._h = None
 
@@ -345,7 +345,7 @@ class Result:
         return out
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:
             lib.vsa_result_free(self._h)
             self._h = None
 
@@ -527,7 +527,7 @@ class Sink:
         return buf[:n].tobytes()
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:
             lib.vsa_sink_close(self._h)
             self._h = None
 
