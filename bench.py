@@ -276,8 +276,9 @@ def main():
                     "instrumented CPU restatement (7.1 kB per 100 bp query "
                     "for all 81 suffixes) scaled to the %.1f%% of the "
                     "suffix searches this kernel executes after the anchor "
-                    "pass and the work plan; the path is random 8-byte reads, one 64-byte "
-                    "sector each (traffic/algorithmic ~ 2), see DESIGN.md"
+                    "pass and the work plan; the path is random 8-byte "
+                    "reads, one 64-byte sector each (traffic/algorithmic "
+                    "~ 1.75), see DESIGN.md"
                     % (100.0 * main_searches / world / full_searches)}
         if world == 1 and a.cpu_sample > 0:
             host.sti1 = index.make_sti1()
@@ -293,6 +294,19 @@ def main():
                           "algorithm 2 = the reference's default -qspeedup 2 "
                           "incl. the MUM filter, %.1f s, %d MUMs"
                           % (sample.nq, dt, len(ref))}
+            # the real reference program, timed once on a GPU box on the
+            # same index and sample size (scripts/cpu_reference_probe.py)
+            rpath = os.path.join(ROOT, "profiles", "cpu_reference.json")
+            if os.path.exists(rpath) and n == 3000000000 and m == 100:
+                with open(rpath) as f:
+                    rj = json.load(f)
+                run = rj["runs"].get("-mum -l %d" % L)
+                if run:
+                    out["cpu_baseline"]["reference_vmatch"] = {
+                        "value": run["queries_per_s"], "unit": "queries/s",
+                        "cores": 1, "kind": "reference",
+                        "sample": "%d queries, %s" % (rj["queries"],
+                                                      rj["source"])}
             out["speedup_vs_cpu_1core"] = qps / (sample.nq / dt)
         print(json.dumps(out), flush=True)
     if world > 1:
