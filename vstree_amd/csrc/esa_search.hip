@@ -26,1377 +26,11 @@
 #define VSA_CURSOR_STRIDE 8   // uint64 words: one cursor per 64-byte line
 #define VSA_CURSOR_SHARDS 2048 // power of two
 
-// ---------------------------------------------------------------------------
-// K1: exact complete matches (Vmengine/exactcompl.c:168-216)
-// ---------------------------------------------------------------------------
-
-// findsufboundaries, Vmengine/exactcompl.c:64-140: widen from the witness to
-// all suffixes sharing >= least symbols, inside the bucket [vleft, vright]
-template <typename IDX, bool KEYED>
-__device__ __forceinline__ void
-vsa_findsufboundaries(const DevIndex<IDX> &ix, uint32_t maxlcp,
-                      uint64_t witness, uint32_t least, uint64_t vleft,
-                      uint64_t vright, uint64_t &l, uint64_t &r)
-{
-  uint64_t i;
-
-  if (maxlcp < 255)
-  {
-    for (i = witness;
-         i != vleft && vsa_lcpbyte<IDX, KEYED>(ix, i) >= (least & 0xFFu); i--)
-    {
-    }
-    l = i;
-    for (i = witness + 1;
-         i <= vright && vsa_lcpbyte<IDX, KEYED>(ix, i) >= (least & 0xFFu); i++)
-    {
-    }
-    r = i - 1;
-  } else
-  {
-    for (i = witness; i != vleft && vsa_evallcp(ix, i) >= least; i--)
-    {
-    }
-    l = i;
-    for (i = witness + 1; i <= vright && vsa_evallcp(ix, i) >= least; i++)
-    {
-    }
-    r = i - 1;
-  }
-}
-
-template <typename IDX, bool DEEP>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_complete_search(const DevIndex<IDX> ix, const DevQueries qs,
-                  uint64_t qlimit, uint64_t *__restrict__ outleft,
-                  uint64_t *__restrict__ outcount)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  const bool active = q < qlimit;
-  const uint8_t *pattern = qs.symbols;
-  uint32_t plen = 0, maxlcp = 0;
-  uint64_t witness = 0, l = 0, count = 0;
-  bool have = false;
-
-  if (active)
-  {
-    if (qs.dense)
-    {
-      pattern = qs.symbols + q * qs.uniformlen;
-      plen = qs.uniformlen;
-    } else
-    {
-      pattern = qs.symbols + qs.start[q];
-      plen = (uint32_t) qs.length[q];
-    }
-  }
-  if constexpr (DEEP)
-  {
-    DeepHit hit;
-    const int st = vsa_locate_deep(ix, active, pattern, plen, maxlcp, witness,
-                                   hit);
-    if (st == VSA_LOC_SLOW)
-    {
-      have = vsa_locate_reference(ix, pattern, plen, maxlcp, witness);
-    } else
-    {
-      have = st == VSA_LOC_FOUND;
-    }
-  } else
-  {
-    if (active)
-    {
-      have = vsa_locate_reference(ix, pattern, plen, maxlcp, witness);
-    }
-  }
-  if (have && maxlcp >= plen)
-  {
-    // the widening stops where lcp < plen, which every bucket boundary
-    // satisfies (lcp < prefixlength <= plen): no need for the bucket here
-    uint64_t r;
-    vsa_findsufboundaries<IDX, DEEP>(ix, maxlcp, witness, plen, 0, ix.n, l,
-                                     r);
-    count = r - l + 1;
-  }
-  if (active)
-  {
-    outleft[q] = l;
-    outcount[q] = count;
-  }
-}
-
-// processfinalexactmatchinterval, Vmengine/exactcompl.c:142-166, for all
-// queries at once: match t belongs to the query whose scanned count range
-// contains t
-template <typename IDX>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_complete_expand(const DevIndex<IDX> ix, const DevQueries qs, uint64_t nq,
-                  const uint64_t *__restrict__ left,
-                  const uint64_t *__restrict__ offsets, uint64_t total,
-                  vsa_match *__restrict__ out)
-{
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-
-  if (t >= total)
-  {
-    return;
-  }
-  // largest q with offsets[q] <= t (offsets has nq+1 entries, last = total)
-  uint64_t lo = 0, hi = nq;
-  while (hi - lo > 1)
-  {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (offsets[mid] <= t)
-    {
-      lo = mid;
-    } else
-    {
-      hi = mid;
-    }
-  }
-  vsa_match m;
-  m.length = qs.length[lo];
-  m.dbstart = (uint64_t) ix.suf[left[lo] + (t - offsets[lo])];
-  m.queryseq = lo + qs.seqoffset;
-  m.querystart = 0;
-  out[t] = m;
-}
-
-// ---------------------------------------------------------------------------
-// K2: matches of all query suffixes (kurtz/matchsub.c:165-235 driving
-// Vmengine/fquery.c:139-270 / :297-386)
-// ---------------------------------------------------------------------------
-
-// macro PROCESSSUFFIX, Vmengine/fquery.c:54-81: a match is reported iff it
-// cannot be extended to the left
-template <typename IDX>
-__device__ __forceinline__ bool vsa_leftmaximal(const DevIndex<IDX> &ix,
-                                                uint64_t sufstart,
-                                                uint8_t leftchar)
-{
-  return sufstart == 0 || VSA_ISSPECIAL(leftchar) ||
-         leftchar != ix.tis[sufstart - 1];
-}
-
-// leftrightsubmatch, Vmengine/fquery.c:139-270 with the bounds algorithm 2
-// passes (left = 0, right = totallength-1, kurtz/matchsub.c:504-515).
-// WRITE = false counts the reports, WRITE = true stores them at out[0..).
-template <typename IDX, bool KEYED, bool WRITE>
-__device__ __forceinline__ uint32_t
-vsa_mem_walk(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness,
-             uint8_t leftchar, uint32_t searchlength, uint64_t qseq,
-             uint64_t qoff, vsa_match *out, uint64_t *outkey, uint64_t key)
-{
-  const uint64_t right = ix.n - 1;
-  uint32_t c = 0, minprefix = maxlcp;
-  uint64_t idx, lcpval;
-
-#define VSA_REPORT(I, LEN)                                                    \
-  {                                                                           \
-    const uint64_t ss_ = vsa_sufstart<IDX, KEYED>(ix, I);                     \
-    if (vsa_leftmaximal(ix, ss_, leftchar))                                   \
-    {                                                                         \
-      if (WRITE)                                                              \
-      {                                                                       \
-        vsa_match m_;                                                         \
-        m_.length = (LEN);                                                    \
-        m_.dbstart = ss_;                                                     \
-        m_.queryseq = qseq;                                                   \
-        m_.querystart = qoff;                                                 \
-        out[c] = m_;                                                          \
-        outkey[c] = key;                                                      \
-      }                                                                       \
-      c++;                                                                    \
-    }                                                                         \
-  }
-
-  for (idx = witness;; idx--)
-  {
-    VSA_REPORT(idx, minprefix);
-    if (idx == 0)
-    {
-      break;
-    }
-    lcpval = (maxlcp < 255) ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, idx)
-                            : vsa_evallcp(ix, idx);
-    if (lcpval < searchlength)
-    {
-      break;
-    }
-    if (minprefix > lcpval)
-    {
-      minprefix = (uint32_t) lcpval;
-    }
-  }
-  minprefix = maxlcp;
-  for (idx = witness + 1; idx <= right; idx++)
-  {
-    lcpval = (maxlcp < 255) ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, idx)
-                            : vsa_evallcp(ix, idx);
-    if (lcpval < searchlength)
-    {
-      break;
-    }
-    if (minprefix > lcpval)
-    {
-      minprefix = (uint32_t) lcpval;
-    }
-    VSA_REPORT(idx, minprefix);
-  }
-#undef VSA_REPORT
-  return c;
-}
-
-// leftrightmaximaluniquematch, Vmengine/fquery.c:297-386, bounds as above.
-// The reference's branch for maxlcp >= 255 looks at the right neighbour only
-// if witness + 1 < right; kept as it stands.
-template <typename IDX, bool KEYED>
-__device__ __forceinline__ bool
-vsa_mum_candidate(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t witness)
-{
-  const uint64_t right = ix.n - 1;
-
-  if (maxlcp < 255)
-  {
-    return (witness == 0 ||
-            vsa_lcpbyte<IDX, KEYED>(ix, witness) < (maxlcp & 0xFFu)) &&
-           (witness + 1 > right ||
-            vsa_lcpbyte<IDX, KEYED>(ix, witness + 1) < (maxlcp & 0xFFu));
-  }
-  bool okay = (witness == 0) || vsa_evallcp(ix, witness) < maxlcp;
-  if (okay && witness + 1 < right)
-  {
-    okay = vsa_evallcp(ix, witness + 1) < maxlcp;
-  }
-  return okay;
-}
-
-// Work-item t of the batch = (query q, offset off).  Queries of one length:
-// arithmetic; ragged batches: binary search in the scanned per-query counts.
-__device__ __forceinline__ void
-vsa_decode_workitem(const DevQueries &qs, const uint64_t *__restrict__ base,
-                    uint32_t perquery, uint64_t t, uint64_t &q, uint32_t &off)
-{
-  if (base == nullptr)
-  {
-    q = t / perquery;
-    off = (uint32_t) (t - q * perquery);
-  } else
-  {
-    uint64_t lo = 0, hi = qs.nq;
-    while (hi - lo > 1)
-    {
-      const uint64_t mid = (lo + hi) >> 1;
-      if (base[mid] <= t)
-      {
-        lo = mid;
-      } else
-      {
-        hi = mid;
-      }
-    }
-    q = lo;
-    off = (uint32_t) (t - base[lo]);
-  }
-}
-
-// [l, r] = all suffixes that share maxlcp symbols with the query, given one
-// of them: neighbours in the suffix array whose lcp is >= maxlcp
-template <typename IDX, bool KEYED>
-__device__ __forceinline__ void
-vsa_maxlcp_interval(const DevIndex<IDX> &ix, uint32_t maxlcp, uint64_t w,
-                    uint64_t &l, uint64_t &r)
-{
-  for (l = w; l > 0; l--)
-  {
-    const uint64_t v = (maxlcp < 255)
-                           ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, l)
-                           : vsa_evallcp(ix, l);
-    if (v < maxlcp)
-    {
-      break;
-    }
-  }
-  for (r = w; r < ix.n; r++)
-  {
-    const uint64_t v = (maxlcp < 255)
-                           ? (uint64_t) vsa_lcpbyte<IDX, KEYED>(ix, r + 1)
-                           : vsa_evallcp(ix, r + 1);
-    if (v < maxlcp)
-    {
-      break;
-    }
-  }
-}
-
-template <typename IDX, bool MUM, bool DEEP, int BLK>
-__global__ void __launch_bounds__(BLK)
-k_query_search(const DevIndex<IDX> ix, const DevQueries qs,
-               const uint64_t *__restrict__ base, uint32_t perquery,
-               const uint32_t *__restrict__ wlq,
-               const uint32_t *__restrict__ wloff, uint64_t nitems,
-               uint32_t searchlength,
-               vsa_match *__restrict__ out, uint64_t *__restrict__ outkey,
-               uint64_t shardcap, uint32_t shardmask,
-               unsigned long long *__restrict__ cursors)
-{
-  uint64_t t = (uint64_t) blockIdx.x * BLK + threadIdx.x;
-  const bool active = t < nitems;
-  uint32_t c = 0, maxlcp = 0, off = 0, remaining = 0;
-  uint64_t witness = 0, q = 0;
-  uint8_t leftchar = (uint8_t) VSA_SEPARATOR;
-  const uint8_t *qptr = qs.symbols;
-  bool have = false, refwitness = true;
-
-  if (active)
-  {
-    if (wlq != nullptr)
-    {
-      // explicit work list (k_mum_anchor / k_expand_worklist); the sort key
-      // stays the number the work-item has in the full (query, offset) grid
-      q = wlq[t];
-      off = wloff[t];
-      t = q * perquery + off;
-    } else
-    {
-      vsa_decode_workitem(qs, base, perquery, t, q, off);
-    }
-    if (qs.dense)
-    {
-      qptr = qs.symbols + q * qs.uniformlen + off;
-      remaining = qs.uniformlen - off;
-    } else
-    {
-      qptr = qs.symbols + qs.start[q] + off;
-      remaining = (uint32_t) qs.length[q] - off;
-    }
-    if (off > 0)
-    {
-      leftchar = qptr[-1];
-    }
-  }
-  DeepHit hit;
-  bool fast = false; // hit holds what the MUM test needs
-  if constexpr (DEEP)
-  {
-    const int st = vsa_locate_deep(ix, active, qptr, remaining, maxlcp,
-                                   witness, hit);
-    if (st == VSA_LOC_SLOW)
-    {
-      have = vsa_locate_reference(ix, qptr, remaining, maxlcp, witness);
-    } else
-    {
-      have = st == VSA_LOC_FOUND;
-      refwitness = false;
-      fast = have && maxlcp < 255;
-    }
-  } else
-  {
-    if (active)
-    {
-      have = vsa_locate_reference(ix, qptr, remaining, maxlcp, witness);
-    }
-  }
-  const bool found = have && maxlcp >= searchlength;
-  if (found)
-  {
-    if (MUM)
-    {
-      if (fast)
-      {
-        // leftrightmaximaluniquematch (fquery.c:297-386) and PROCESSSUFFIX
-        // (fquery.c:54-81) on values already in registers
-        const uint32_t lcpw = (uint32_t) (hit.ew >> 32) & 0xFFu;
-        const uint64_t ss = hit.ew & 0xFFFFFFFFull;
-        const bool unique = (witness == 0 || lcpw < maxlcp) &&
-                            (witness + 1 > ix.n - 1 || hit.lcpnext < maxlcp);
-        c = (unique && (ss == 0 || VSA_ISSPECIAL(leftchar) ||
-                        leftchar != hit.leftsym))
-                ? 1u
-                : 0u;
-      } else
-      {
-        c = (vsa_mum_candidate<IDX, DEEP>(ix, maxlcp, witness) &&
-             vsa_leftmaximal(ix, vsa_sufstart<IDX, DEEP>(ix, witness),
-                             leftchar))
-                ? 1u
-                : 0u;
-      }
-    } else
-    {
-      if (!refwitness)
-      {
-        // the enumeration starts at the reference's witness
-        uint64_t l, r, vleft, vright;
-        vsa_maxlcp_interval<IDX, DEEP>(ix, maxlcp, witness, l, r);
-        if (l != r && vsa_bucket(ix, qptr, vleft, vright))
-        {
-          witness = vsa_reference_witness(vleft, vright, l, r);
-        }
-      }
-      c = vsa_mem_walk<IDX, DEEP, false>(ix, maxlcp, witness, leftchar,
-                                         searchlength, q, off, nullptr,
-                                         nullptr, t);
-    }
-  }
-  // all 64 lanes arrive here.  Output space comes from one of many cursors
-  // (one 64-byte line each, picked by workgroup number): a single cursor
-  // word takes ~11 ns per returning atomic, which for 10^7 wavefronts is
-  // longer than the whole search.  The regions are compacted afterwards.
-  const uint32_t shard = blockIdx.x & shardmask;
-  const uint64_t inshard =
-      vsa_wave_reserve(cursors + (uint64_t) shard * VSA_CURSOR_STRIDE, c);
-  if (c > 0 && inshard + c <= shardcap)
-  {
-    const uint64_t mybase = (uint64_t) shard * shardcap + inshard;
-    if (MUM)
-    {
-      vsa_match m;
-      m.length = maxlcp;
-      m.dbstart = fast ? (hit.ew & 0xFFFFFFFFull)
-                       : vsa_sufstart<IDX, DEEP>(ix, witness);
-      m.queryseq = q + qs.seqoffset;
-      m.querystart = off;
-      out[mybase] = m;
-      outkey[mybase] = t;
-    } else
-    {
-      vsa_mem_walk<IDX, DEEP, true>(ix, maxlcp, witness, leftchar,
-                                    searchlength, q + qs.seqoffset, off,
-                                    out + mybase, outkey + mybase, t);
-    }
-  }
-}
-
-// gathers the filled part of every cursor region into one dense list
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_compact_shards(const vsa_match *__restrict__ in,
-                 const uint64_t *__restrict__ inkey, uint64_t shardcap,
-                 const unsigned long long *__restrict__ cursors,
-                 const uint64_t *__restrict__ offsets,
-                 vsa_match *__restrict__ out, uint64_t *__restrict__ outkey)
-{
-  const uint32_t shard = blockIdx.x;
-  const uint64_t count = cursors[(uint64_t) shard * VSA_CURSOR_STRIDE],
-                 src = (uint64_t) shard * shardcap, dst = offsets[shard];
-  for (uint64_t i = threadIdx.x; i < count; i += VSA_BLOCK)
-  {
-    out[dst + i] = in[src + i];
-    outkey[dst + i] = inkey[src + i];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// MUM work reduction.  If the query suffix at offset j matches the text up to
-// the END of the query, no offset j' > j of that query can produce a MUM
-// candidate: its longest match is the rest of the query as well, and if that
-// match is unique in the index it is the one at (position + j' - j), whose
-// left neighbour is the matched query symbol, so the test of
-// leftrightmaximaluniquematch / PROCESSSUFFIX (Vmengine/fquery.c:54-81,
-// 297-386) rejects it; if it is not unique it is rejected as well.  (The
-// reference's own algorithm 2 exploits the same suffix-link structure,
-// kurtz/matchsub.c:400-491.)  So: locate the LAST offset of every query; if
-// it matches completely, walk that occurrence backwards through the text as
-// far as it agrees with the query -- down to offset m -- and only offsets
-// 0..m need a search.  Queries that match end to end cost 2 searches instead
-// of (length - l + 1).
-// ---------------------------------------------------------------------------
-
-template <typename IDX, bool DEEP>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_anchor(const DevIndex<IDX> ix, const DevQueries qs, uint32_t perquery,
-             uint32_t searchlength, uint32_t *__restrict__ count)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  const bool active = q < qs.nq && perquery > 0;
-  const uint32_t lastoff = perquery > 0 ? perquery - 1 : 0;
-  const uint8_t *qstart = qs.symbols, *qptr = qs.symbols;
-  uint32_t maxlcp = 0;
-  uint64_t witness = 0, sufstart = 0;
-  bool have = false;
-
-  if (active)
-  {
-    qstart = qs.dense ? qs.symbols + q * qs.uniformlen
-                      : qs.symbols + qs.start[q];
-    qptr = qstart + lastoff;
-  }
-  if constexpr (DEEP)
-  {
-    DeepHit hit;
-    const int st = vsa_locate_deep(ix, active, qptr, searchlength, maxlcp,
-                                   witness, hit);
-    if (st == VSA_LOC_SLOW)
-    {
-      have = vsa_locate_reference(ix, qptr, searchlength, maxlcp, witness);
-      sufstart = have ? (uint64_t) ix.suf[witness] : 0;
-    } else
-    {
-      have = st == VSA_LOC_FOUND;
-      sufstart = hit.ew & 0xFFFFFFFFull;
-    }
-  } else
-  {
-    if (active)
-    {
-      have = vsa_locate_reference(ix, qptr, searchlength, maxlcp, witness);
-      sufstart = have ? (uint64_t) ix.suf[witness] : 0;
-    }
-  }
-  if (!active)
-  {
-    return;
-  }
-  uint32_t need = perquery;
-  if (have && maxlcp >= searchlength)
-  {
-    // walk backwards: query[lastoff-1-k] against text[sufstart-1-k]; the
-    // text has 0xFF in front of position 0, specials never match
-    uint32_t k = 0;
-    while (k < lastoff)
-    {
-      const uint32_t room = lastoff - k; // query symbols still available
-      if (room >= 32)
-      {
-        // 32 symbols per round trip, most recent first
-        uint64_t m[4];
-        {
-          // bytes [-32, 0) in front of the current position, two 16-byte
-          // loads per side; word 0 = the most recent eight symbols
-          const vsa_u128 qn = vsa_load16(qptr - k - 16),
-                         qf = vsa_load16(qptr - k - 32),
-                         tn = vsa_load16(ix.tis + sufstart - k - 16),
-                         tf = vsa_load16(ix.tis + sufstart - k - 32);
-          const uint64_t a[4] = {qn.hi, qn.lo, qf.hi, qf.lo},
-                         b[4] = {tn.hi, tn.lo, tf.hi, tf.lo};
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-          {
-            m[i] = (a[i] ^ b[i]) | vsa_specialmask(a[i]) |
-                   vsa_specialmask(b[i]);
-          }
-        }
-        if ((m[0] | m[1] | m[2] | m[3]) == 0)
-        {
-          k += 32;
-          continue;
-        }
-        const int i = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
-        const uint64_t mm = m[0] ? m[0] : (m[1] ? m[1] : (m[2] ? m[2] : m[3]));
-        k += 8 * i + ((uint32_t) __builtin_clzll(mm) >> 3);
-        break;
-      } else if (room >= 8)
-      {
-        const uint64_t a = vsa_load8(qptr - k - 8),
-                       b = vsa_load8(ix.tis + sufstart - k - 8);
-        const uint64_t m = (a ^ b) | vsa_specialmask(a) | vsa_specialmask(b);
-        if (m != 0)
-        {
-          k += (uint32_t) __builtin_clzll(m) >> 3; // matching bytes from top
-          break;
-        }
-        k += 8;
-      } else
-      {
-        const uint8_t a = qptr[-(int64_t) k - 1],
-                      b = ix.tis[(int64_t) sufstart - (int64_t) k - 1];
-        if (a != b || VSA_ISSPECIAL(a))
-        {
-          break;
-        }
-        k++;
-      }
-    }
-    need = lastoff - k + 1; // offsets 0 .. lastoff-k
-  }
-  count[q] = need;
-}
-
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_expand_worklist(const uint32_t *__restrict__ count,
-                  const uint64_t *__restrict__ wbase, uint64_t nq,
-                  uint32_t *__restrict__ wlq, uint32_t *__restrict__ wloff)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (q >= nq)
-  {
-    return;
-  }
-  const uint32_t c = count[q];
-  const uint64_t b = wbase[q];
-  for (uint32_t j = 0; j < c; j++)
-  {
-    wlq[b + j] = (uint32_t) q;
-    wloff[b + j] = j;
-  }
-}
-
-// ---- MUM work plan -------------------------------------------------------
-//
-// e(j) = j + (length of the longest match of the query suffix at offset j)
-// never decreases with j, and an offset whose e equals that of the offset in
-// front of it cannot be a MUM candidate: its longest match is the one of its
-// predecessor moved by one symbol, so it is either not unique or not left
-// maximal (leftrightmaximaluniquematch / PROCESSSUFFIX, fquery.c:54-81,
-// 297-386; the reference's default algorithm 2 rides the same suffix links,
-// matchsub.c:400-491).  So after the suffix at offset j has been located,
-// with E = e(j): if the suffix at jp = E + 1 - l (the last one whose first l
-// symbols end at E) also stops at E, every offset in (j, jp] stops at E and
-// is dead; the offsets (jp, E] have to be searched, and E + 1 starts afresh.
-// A read with one substitution at x costs 1 + l searches instead of x + 2.
-//
-// A plan is at most VSA_PLAN_RANGES ranges of offsets per query, 16 bits
-// each for first offset and length.
-
-#define VSA_PLAN_RANGES 4
-#define VSA_PLAN_ROUNDS 6
-#define VSA_PLAN_UNKNOWN 0xFFFFFFFFu
-
-struct PlanRanges
-{
-  uint32_t r[VSA_PLAN_RANGES]; // first | length << 16
-};
-
-__device__ __forceinline__ void plan_add(PlanRanges &pr, uint32_t &nr,
-                                         uint32_t first, uint32_t last)
-{
-  // [first, last], behind everything added so far
-  if (first > last)
-  {
-    return;
-  }
-  if (nr > 0)
-  {
-    const uint32_t pf = pr.r[nr - 1] & 0xFFFFu, pl = pr.r[nr - 1] >> 16;
-    if (pf + pl == first || nr == VSA_PLAN_RANGES)
-    {
-      // contiguous, or no slot left: extend the last range up to here
-      // (searching a dead offset is harmless, it reports nothing)
-      pr.r[nr - 1] = pf | ((last - pf + 1) << 16);
-      return;
-    }
-  }
-  pr.r[nr++] = first | ((last - first + 1) << 16);
-}
-
-// default plan of every query: offsets 0 .. need-1
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_plan_default(const uint32_t *__restrict__ count, uint64_t nq,
-               PlanRanges *__restrict__ plan)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (q < nq)
-  {
-    PlanRanges pr;
-    pr.r[0] = count[q] << 16;
-#pragma unroll
-    for (int i = 1; i < VSA_PLAN_RANGES; i++)
-    {
-      pr.r[i] = 0;
-    }
-    plan[q] = pr;
-  }
-}
-
-// one work-item per listed query (those with many offsets to search)
-template <typename IDX, bool DEEP>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_plan(const DevIndex<IDX> ix, const DevQueries qs,
-           const uint32_t *__restrict__ list, uint64_t nlist,
-           uint32_t searchlength, const uint32_t *__restrict__ firste,
-           uint32_t *__restrict__ count, PlanRanges *__restrict__ plan)
-{
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  bool busy = t < nlist;
-  uint64_t q = 0;
-  uint32_t need = 0, j = 0, nr = 0;
-  // offset 0 has been located by k_mum_first: its e is known, and it is
-  // not searched again
-  uint32_t e0 = VSA_PLAN_UNKNOWN;
-  const uint32_t qlen = qs.uniformlen;
-  const uint8_t *qstart = qs.symbols;
-  PlanRanges pr;
-
-#pragma unroll
-  for (int i = 0; i < VSA_PLAN_RANGES; i++)
-  {
-    pr.r[i] = 0;
-  }
-  if (busy)
-  {
-    q = list[t];
-    need = count[q];
-    qstart = qs.dense ? qs.symbols + q * qs.uniformlen
-                      : qs.symbols + qs.start[q];
-    if (firste != nullptr)
-    {
-      e0 = firste[q];
-    }
-  }
-  for (int round = 0; round < VSA_PLAN_ROUNDS && __any(busy); round++)
-  {
-    // A: the suffix at offset j
-    uint32_t maxlcp = 0, maxlcp2 = 0;
-    uint64_t witness = 0;
-    bool have = false, have2 = false;
-    const bool known = round == 0 && e0 != VSA_PLAN_UNKNOWN;
-    if (busy && !known && need - j <= 2)
-    {
-      plan_add(pr, nr, j, need - 1); // nothing to gain any more
-      busy = false;
-    }
-    if constexpr (DEEP)
-    {
-      DeepHit hit;
-      const int st = vsa_locate_deep(ix, busy && !known, qstart + j, qlen - j,
-                                     maxlcp, witness, hit);
-      if (st == VSA_LOC_SLOW)
-      {
-        have = vsa_locate_reference(ix, qstart + j, qlen - j, maxlcp, witness);
-      } else
-      {
-        have = st == VSA_LOC_FOUND;
-      }
-    } else
-    {
-      if (busy && !known)
-      {
-        have = vsa_locate_reference(ix, qstart + j, qlen - j, maxlcp, witness);
-      }
-    }
-    if (known)
-    {
-      have = true;
-      maxlcp = e0;
-    }
-    uint32_t E = 0, jp = 0;
-    bool probe = false;
-    if (busy)
-    {
-      if (!known)
-      {
-        plan_add(pr, nr, j, j);
-      }
-      if (!have)
-      {
-        // fewer than prefixlength symbols match: no exact E; the offsets
-        // up to there are searched, the next round starts behind them
-        const uint32_t last = (j + ix.pl - 1 < need - 1) ? j + ix.pl - 1
-                                                         : need - 1;
-        plan_add(pr, nr, j + 1, last);
-        j = last + 1;
-        busy = j < need;
-      } else
-      {
-        E = j + maxlcp;
-        if (E >= qlen)
-        {
-          busy = false; // matches to the end: every later offset is dead
-        } else
-        {
-          probe = E + 1 >= searchlength + j + 3 &&
-                  E + 1 - searchlength < need;
-          jp = probe ? E + 1 - searchlength : 0;
-        }
-      }
-    }
-    // B: the probe at jp
-    const bool doprobe = busy && have && probe;
-    if constexpr (DEEP)
-    {
-      DeepHit hit;
-      const int st = vsa_locate_deep(ix, doprobe, qstart + jp, qlen - jp,
-                                     maxlcp2, witness, hit);
-      if (st == VSA_LOC_SLOW)
-      {
-        have2 = vsa_locate_reference(ix, qstart + jp, qlen - jp, maxlcp2,
-                                     witness);
-      } else
-      {
-        have2 = st == VSA_LOC_FOUND;
-      }
-    } else
-    {
-      if (doprobe)
-      {
-        have2 = vsa_locate_reference(ix, qstart + jp, qlen - jp, maxlcp2,
-                                     witness);
-      }
-    }
-    if (busy && have)
-    {
-      const bool dead = doprobe && have2 && jp + maxlcp2 == E;
-      const uint32_t first = dead ? jp + 1 : j + 1;
-      const uint32_t last = (E < need - 1) ? E : need - 1;
-      plan_add(pr, nr, first, last);
-      j = E + 1;
-      busy = j < need;
-    }
-  }
-  if (t < nlist)
-  {
-    if (busy)
-    {
-      plan_add(pr, nr, j, need - 1); // out of rounds: search the rest
-    }
-    uint32_t total = 0;
-#pragma unroll
-    for (int i = 0; i < VSA_PLAN_RANGES; i++)
-    {
-      total += pr.r[i] >> 16;
-    }
-    plan[q] = pr;
-    count[q] = total;
-  }
-}
-
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_expand_plan(const PlanRanges *__restrict__ plan,
-              const uint64_t *__restrict__ wbase, uint64_t nq,
-              uint32_t *__restrict__ wlq, uint32_t *__restrict__ wloff)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (q >= nq)
-  {
-    return;
-  }
-  const PlanRanges pr = plan[q];
-  uint64_t b = wbase[q];
-#pragma unroll
-  for (int i = 0; i < VSA_PLAN_RANGES; i++)
-  {
-    const uint32_t first = pr.r[i] & 0xFFFFu, len = pr.r[i] >> 16;
-    for (uint32_t j = 0; j < len; j++)
-    {
-      wlq[b] = (uint32_t) q;
-      wloff[b] = first + j;
-      b++;
-    }
-  }
-}
-
-
-// The first pass of a MUM batch: offset 0 of every query, located with the
-// whole query.  A query that matches completely is finished here: e(0) is
-// the end of the query, so no later offset can be a candidate (see above),
-// and offset 0 is one iff its match is unique -- its left neighbour is the
-// start of the query, which PROCESSSUFFIX treats as left maximal
-// (fquery.c:54-81).  That is one search for an exact read instead of two
-// (last offset + offset 0) and a backward walk.  For the others e(0) goes to
-// the work plan.
-template <typename IDX, bool DEEP>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_first(const DevIndex<IDX> ix, const DevQueries qs, uint32_t perquery,
-            uint32_t searchlength, uint32_t *__restrict__ count,
-            uint32_t *__restrict__ firste, uint32_t *__restrict__ fmlen,
-            uint64_t *__restrict__ fmdb)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  const bool active = q < qs.nq && perquery > 0;
-  const uint32_t qlen = qs.uniformlen;
-  const uint8_t *qptr = qs.symbols;
-  uint32_t maxlcp = 0;
-  uint64_t witness = 0;
-  bool have = false, fast = false;
-  DeepHit hit;
-
-  if (active)
-  {
-    qptr = qs.dense ? qs.symbols + q * qs.uniformlen
-                    : qs.symbols + qs.start[q];
-  }
-  if constexpr (DEEP)
-  {
-    const int st = vsa_locate_deep(ix, active, qptr, qlen, maxlcp, witness,
-                                   hit);
-    if (st == VSA_LOC_SLOW)
-    {
-      have = vsa_locate_reference(ix, qptr, qlen, maxlcp, witness);
-    } else
-    {
-      have = st == VSA_LOC_FOUND;
-      fast = have && maxlcp < 255;
-    }
-  } else
-  {
-    if (active)
-    {
-      have = vsa_locate_reference(ix, qptr, qlen, maxlcp, witness);
-    }
-  }
-  if (!active)
-  {
-    return;
-  }
-  uint32_t len = 0;
-  uint64_t db = 0;
-  if (have && maxlcp >= searchlength)
-  {
-    bool unique;
-    if (fast)
-    {
-      const uint32_t lcpw = (uint32_t) (hit.ew >> 32) & 0xFFu;
-      unique = (witness == 0 || lcpw < maxlcp) &&
-               (witness + 1 > ix.n - 1 || hit.lcpnext < maxlcp);
-      db = hit.ew & 0xFFFFFFFFull;
-    } else
-    {
-      unique = vsa_mum_candidate<IDX, DEEP>(ix, maxlcp, witness);
-      db = vsa_sufstart<IDX, DEEP>(ix, witness);
-    }
-    len = unique ? maxlcp : 0;
-  }
-  fmlen[q] = len;
-  fmdb[q] = db;
-  firste[q] = have ? maxlcp : VSA_PLAN_UNKNOWN;
-  count[q] = (have && maxlcp >= qlen) ? 0 : perquery;
-}
-
-// candidates of the first pass -> behind the matches of the search kernel,
-// with the sort key of work-item (query, offset 0)
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_append_first(const uint32_t *__restrict__ fmlen,
-               const uint64_t *__restrict__ fmdb,
-               const uint32_t *__restrict__ slot, uint64_t nq,
-               uint32_t perquery, uint64_t seqoffset, uint64_t base,
-               vsa_match *__restrict__ out, uint64_t *__restrict__ outkey)
-{
-  const uint64_t q = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (q < nq && fmlen[q] != 0)
-  {
-    vsa_match m;
-    m.length = fmlen[q];
-    m.dbstart = fmdb[q];
-    m.queryseq = q + seqoffset;
-    m.querystart = 0;
-    out[base + slot[q]] = m;
-    outkey[base + slot[q]] = q * perquery;
-  }
-}
-
-struct NonZeroToU32
-{
-  __device__ uint32_t operator()(uint32_t v) const
-  {
-    return v != 0 ? 1u : 0u;
-  }
-};
-
-struct PlanWanted
-{
-  const uint32_t *count;
-  uint32_t threshold;
-  __device__ bool operator()(uint32_t q) const
-  {
-    return count[q] > threshold;
-  }
-};
-
-// ---------------------------------------------------------------------------
-// K4: MUM candidates -> MUMs (kurtz/cleanMUMcand.c:55-118)
-// ---------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_keys(const vsa_match *__restrict__ cand, uint64_t n,
-           uint64_t *__restrict__ keylen, uint64_t *__restrict__ keydb)
-{
-  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (i < n)
-  {
-    keylen[i] = ~cand[i].length; // decreasing length
-    keydb[i] = cand[i].dbstart;
-  }
-}
-
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_rightends(const vsa_match *__restrict__ cand, uint64_t n,
-                uint64_t *__restrict__ rightend)
-{
-  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (i < n)
-  {
-    rightend[i] = cand[i].dbstart + cand[i].length - 1;
-  }
-}
-
-// dbright[i] = max(0, rightend[0..i)) is what the reference's running
-// variable holds when it looks at candidate i.  Candidate i survives iff it
-// is not covered (dbright < rightend) and its successor does not end at the
-// same position with the same start.
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_flags(const vsa_match *__restrict__ cand,
-            const uint64_t *__restrict__ rightend,
-            const uint64_t *__restrict__ dbright, uint64_t n,
-            uint8_t *__restrict__ keep)
-{
-  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (i >= n)
-  {
-    return;
-  }
-  bool k = dbright[i] < rightend[i];
-  if (k && i + 1 < n)
-  {
-    // dbright[i+1] = rightend[i] here
-    if (rightend[i + 1] == rightend[i] &&
-        cand[i + 1].dbstart == cand[i].dbstart)
-    {
-      k = false;
-    }
-  }
-  keep[i] = k ? 1 : 0;
-}
-
-// ---------------------------------------------------------------------------
-// K3: MUMs on an index that contains its queries (Vmengine/fmumself.c:10-66)
-// ---------------------------------------------------------------------------
-
-// K3a  k_selfmum_peaks: the streaming pass.  A workgroup takes 16 KiB of
-//      lcptab (256 work-items x 4 x one 128-bit load, consecutive lanes on
-//      consecutive 16-byte pieces), every work-item tests its 64 positions on
-//      the lcp bytes alone -- "second >= l, first < second, third < second"
-//      (fmumself.c:36-37) -- and the positions that pass (or that need the
-//      exception table because a byte is 255) and whose two suffixes differ
-//      in the symbol to their left (bwt, streamed alongside) leave through
-//      ONE cursor reservation per workgroup.  2n bytes in, 4 bytes out per
-//      surviving peak.
-// K3b  k_selfmum_emit: one work-item per peak (sorted by position): exact lcp
-//      values, the two suffix starts, the db/query sides, left maximality on
-//      bwt; writes the match and a keep flag, compacted in order afterwards.
-
-
-// Four suffix array positions per 32-bit operation.  All helpers deliver
-// their verdict in bit 7 of each byte and leave the other bits undefined.
-#define VSA_B7 0x80808080u
-#define VSA_L7 0x7F7F7F7Fu
-
-// (m & a) | (~m & b), one v_bfi_b32
-__device__ __forceinline__ uint32_t vsa_bfi(uint32_t m, uint32_t a, uint32_t b)
-{
-  return (m & a) | (~m & b);
-}
-
-// bytewise unsigned x < y; ylow = y & VSA_L7.  Where the top bits differ y's
-// top bit decides, elsewhere the carry of ylow + (127 - xlow) into bit 7.
-__device__ __forceinline__ uint32_t vsa_bytes_lt(uint32_t x, uint32_t y,
-                                                 uint32_t ylow)
-{
-  return vsa_bfi(x ^ y, y, ylow + (~x & VSA_L7));
-}
-
-// The peak test of fmumself.c:36-37,50-52 on four suffix array positions:
-// s = lcp bytes of the four centres, f / t = their left / right neighbours,
-// a / b = bwt of the two suffixes of each centre.  Exact on bytes below 255;
-// a centre of 255 always passes and is resolved through llv by k_selfmum_emit.
-// ltmin = vsa_bytes_lt(s, l, ...) comes from the caller, which has it already.
-__device__ __forceinline__ uint32_t
-vsa_peakbits4(uint32_t f, uint32_t s, uint32_t t, uint32_t a, uint32_t b,
-              uint32_t ltmin)
-{
-  const uint32_t slow = s & VSA_L7;
-  const uint32_t is255 = (slow + 0x01010101u) & s;
-  const uint32_t peak = vsa_bytes_lt(f, s, slow) & vsa_bytes_lt(t, s, slow);
-  const uint32_t x = a ^ b;
-  const uint32_t differ = ((x & VSA_L7) + VSA_L7) | x;    // bwt bytes differ
-  const uint32_t special = ((a & VSA_L7) + 0x02020202u) & a; // a >= 254
-  return (is255 | peak) & ~ltmin & (differ | special);
-}
-
-// 16 aligned bytes of a table that is read once (NT: nontemporal hint)
-template <bool NT>
-__device__ __forceinline__ uint4 vsa_stream16(const uint8_t *ptr)
-{
-  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-  const v4u *q = reinterpret_cast<const v4u *>(ptr);
-  const v4u r = NT ? __builtin_nontemporal_load(q) : *q;
-  return make_uint4(r.x, r.y, r.z, r.w);
-}
-
-// One wavefront = one tile of (64 * PIECES * 16) suffix array positions at a time;
-// wavefronts walk the tiles grid-stride and never synchronise with each other
-// (no LDS, no barrier).  The loads of the NEXT tile are issued before the
-// current one is examined, so that the arithmetic (about 11 operations per
-// position when every word has an lcp byte >= l, i.e. two near-identical
-// genomes) overlaps the memory stream instead of alternating with it.  A word
-// of four positions runs the full test only if one of its lcp bytes is >= l.
-template <int PIECES>
-struct PeakTile
-{
-  uint4 v[PIECES], u[PIECES];
-  uint32_t lcpbefore, bwtbefore, lcpafter; // halo words, valid in every lane
-};
-
-template <int PIECES, bool NT>
-__device__ __forceinline__ void
-vsa_peak_load(PeakTile<PIECES> &t, const uint8_t *__restrict__ lcp,
-              const uint8_t *__restrict__ bwt, uint64_t n, uint64_t base,
-              uint32_t lane)
-{
-  // lcp and bwt have n+1 entries and at least 32 bytes of slack behind them;
-  // reads beyond that are clamped away
-#pragma unroll
-  for (int p = 0; p < PIECES; p++)
-  {
-    const uint64_t off = base + ((uint64_t) p * 64 + lane) * 16;
-    const bool inside = off <= n;
-    t.v[p] = inside ? vsa_stream16<NT>(lcp + off) : make_uint4(0, 0, 0, 0);
-    t.u[p] = inside ? vsa_stream16<NT>(bwt + off) : make_uint4(0, 0, 0, 0);
-  }
-  t.lcpbefore =
-      (base >= 4) ? *reinterpret_cast<const uint32_t *>(lcp + base - 4) : 0u;
-  t.bwtbefore =
-      (base >= 4) ? *reinterpret_cast<const uint32_t *>(bwt + base - 4) : 0u;
-  t.lcpafter = (base + (64 * PIECES * 16) <= n)
-                   ? *reinterpret_cast<const uint32_t *>(lcp + base +
-                                                         (64 * PIECES * 16))
-                   : 0u;
-}
-
-template <int PIECES, bool NT>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_selfmum_peaks(const uint8_t *__restrict__ lcp,
-                const uint8_t *__restrict__ bwt, uint64_t n,
-                uint32_t slmin, uint32_t *__restrict__ outpos,
-                uint64_t shardcap, uint32_t shardmask,
-                unsigned long long *__restrict__ cursors, uint64_t ntiles)
-{
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t nwaves = (uint64_t) gridDim.x * (VSA_BLOCK / 64);
-  const uint32_t minv = slmin * 0x01010101u;
-  uint64_t tile = (uint64_t) blockIdx.x * (VSA_BLOCK / 64) + (threadIdx.x >> 6);
-  const uint32_t shard = (uint32_t) tile & shardmask;
-  PeakTile<PIECES> cur;
-
-  if (tile >= ntiles)
-  {
-    return;
-  }
-  vsa_peak_load<PIECES, NT>(cur, lcp, bwt, n, tile * (64 * PIECES * 16), lane);
-  while (true)
-  {
-    const uint64_t next = tile + nwaves, base = tile * (64 * PIECES * 16);
-    PeakTile<PIECES> nxt;
-    if (next < ntiles)
-    {
-      vsa_peak_load<PIECES, NT>(nxt, lcp, bwt, n, next * (64 * PIECES * 16), lane);
-    }
-    uint32_t hits[PIECES];
-    uint32_t c = 0;
-#pragma unroll
-    for (int p = 0; p < PIECES; p++)
-    {
-      const uint64_t off = base + ((uint64_t) p * 64 + lane) * 16;
-      // the words around this piece live in the neighbouring lanes
-      uint32_t wb = __shfl_up(cur.v[p].w, 1, 64),
-               bb = __shfl_up(cur.u[p].w, 1, 64),
-               wa = __shfl_down(cur.v[p].x, 1, 64);
-      if (lane == 0)
-      {
-        wb = (p > 0) ? (uint32_t) __builtin_amdgcn_readlane(
-                           (int) cur.v[p > 0 ? p - 1 : 0].w, 63)
-                     : cur.lcpbefore;
-        bb = (p > 0) ? (uint32_t) __builtin_amdgcn_readlane(
-                           (int) cur.u[p > 0 ? p - 1 : 0].w, 63)
-                     : cur.bwtbefore;
-      }
-      if (lane == 63)
-      {
-        wa = (p + 1 < PIECES)
-                 ? (uint32_t) __builtin_amdgcn_readlane(
-                       (int) cur.v[p + 1 < PIECES ? p + 1 : p].x, 0)
-                 : cur.lcpafter;
-      }
-      const uint32_t w[6] = {wb, cur.v[p].x, cur.v[p].y, cur.v[p].z,
-                             cur.v[p].w, wa};
-      const uint32_t b[5] = {bb, cur.u[p].x, cur.u[p].y, cur.u[p].z,
-                             cur.u[p].w};
-      // verdict of centre off + 4k + i lands in bit 8i + 7 - k of h
-      uint32_t h = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-      {
-        const uint32_t ltmin = vsa_bytes_lt(w[k + 1], minv, minv & VSA_L7);
-        if ((ltmin & VSA_B7) != VSA_B7) // some lcp byte >= l
-        {
-          const uint32_t x =
-              vsa_peakbits4(__builtin_amdgcn_alignbit(w[k + 1], w[k], 24),
-                            w[k + 1],
-                            __builtin_amdgcn_alignbit(w[k + 2], w[k + 1], 8),
-                            b[k + 1],
-                            __builtin_amdgcn_alignbit(b[k + 1], b[k], 24),
-                            ltmin);
-          h |= (x >> k) & (VSA_B7 >> k);
-        }
-      }
-      // centres j with 1 <= j <= n-2 (the reference's i = j+1 runs 2 .. n-1)
-      if (off == 0)
-      {
-        h &= ~0x80u;
-      }
-      if (off + 17 > n)
-      {
-        uint32_t valid = 0;
-        for (uint32_t q = 0; q < 16 && off + q + 2 <= n; q++)
-        {
-          valid |= 1u << (8 * (q & 3u) + 7 - (q >> 2));
-        }
-        h &= valid;
-      }
-      hits[p] = h;
-      c += (uint32_t) __builtin_popcount(h);
-    }
-    // wavefront-wide exclusive scan of c, one reservation per wavefront
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-      const uint32_t o = __shfl_up(incl, d, 64);
-      if (lane >= (uint32_t) d)
-      {
-        incl += o;
-      }
-    }
-    const uint32_t total = __shfl(incl, 63, 64);
-    if (total > 0)
-    {
-      unsigned long long wbase = 0;
-      if (lane == 0)
-      {
-        wbase = atomicAdd(cursors + (uint64_t) shard * VSA_CURSOR_STRIDE,
-                          (unsigned long long) total);
-      }
-      wbase = __shfl(wbase, 0, 64);
-      if (c > 0 && wbase + total <= shardcap)
-      {
-        uint32_t *dst = outpos + (uint64_t) shard * shardcap;
-        uint64_t slot = wbase + incl - c;
-#pragma unroll
-        for (int p = 0; p < PIECES; p++)
-        {
-          // position reported = j + 1, as the reference counts it
-          const uint64_t first = base + ((uint64_t) p * 64 + lane) * 16 + 1;
-          uint32_t h = hits[p];
-          while (h != 0)
-          {
-            const uint32_t bit = (uint32_t) __builtin_ctz(h);
-            h &= h - 1;
-            dst[slot++] = (uint32_t) (first + 4 * (7 - (bit & 7u)) + (bit >> 3));
-          }
-        }
-      }
-    }
-    if (next >= ntiles)
-    {
-      break;
-    }
-    cur = nxt;
-    tile = next;
-  }
-}
-
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_gather_u32_shards(const uint32_t *__restrict__ in, uint64_t shardcap,
-                    const unsigned long long *__restrict__ cursors,
-                    const uint64_t *__restrict__ offsets,
-                    uint32_t *__restrict__ out)
-{
-  const uint32_t shard = blockIdx.x;
-  const uint64_t count = cursors[(uint64_t) shard * VSA_CURSOR_STRIDE],
-                 src = (uint64_t) shard * shardcap, dst = offsets[shard];
-  for (uint64_t i = threadIdx.x; i < count; i += VSA_BLOCK)
-  {
-    out[dst + i] = in[src + i];
-  }
-}
-
-template <typename IDX>
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_selfmum_emit(const DevIndex<IDX> ix, const uint32_t *__restrict__ peaks,
-               uint64_t npeaks, uint64_t searchlength,
-               uint64_t querysepposition, vsa_match *__restrict__ out,
-               uint8_t *__restrict__ keep)
-{
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (t >= npeaks)
-  {
-    return;
-  }
-  const uint64_t i = peaks[t];
-  uint64_t first = ix.lcp[i - 2], second = ix.lcp[i - 1], third = ix.lcp[i];
-  // SEQUENTIALEVALLCPVALUE (virtualdef.h:121-136) by index instead of in
-  // sequence
-  if (first == 255)
-  {
-    first = vsa_largelcp(ix, i - 2);
-  }
-  if (second == 255)
-  {
-    second = vsa_largelcp(ix, i - 1);
-  }
-  if (third == 255)
-  {
-    third = vsa_largelcp(ix, i);
-  }
-  bool ok = second >= searchlength && first < second && third < second;
-  vsa_match m;
-  m.length = second;
-  m.dbstart = m.queryseq = m.querystart = 0;
-  if (ok)
-  {
-    uint64_t s1 = (uint64_t) ix.suf[i - 2], s2 = (uint64_t) ix.suf[i - 1];
-    if (s1 > s2)
-    {
-      const uint64_t tmp = s1;
-      s1 = s2;
-      s2 = tmp;
-    }
-    // left maximality (fmumself.c:50-52) was decided exactly by the peak
-    // pass: the suffix at text position 0 carries bwt 253, which differs
-    // from every symbol, so that "start1 == 0" needs no case of its own
-    ok = s1 < querysepposition && s2 > querysepposition;
-    m.dbstart = s1;
-    m.queryseq = s2;
-  }
-  out[t] = m;
-  keep[t] = ok ? 1 : 0;
-}
-
-struct KeepToU32
-{
-  __device__ uint32_t operator()(uint8_t k) const
-  {
-    return k;
-  }
-};
-
-// order-preserving compaction of 32-byte records: slot[] = exclusive scan of
-// keep[] (rocprim::select moves records of this size at a fraction of the
-// memory rate: 3.6 ms for 15.6 M records, this pair of passes 0.2 ms)
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_scatter_kept(const vsa_match *__restrict__ in,
-               const uint8_t *__restrict__ keep,
-               const uint32_t *__restrict__ slot, uint64_t count,
-               vsa_match *__restrict__ out, uint64_t *__restrict__ nkept)
-{
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (t >= count)
-  {
-    return;
-  }
-  const uint32_t k = keep[t], s = slot[t];
-  if (k != 0)
-  {
-    const uint4 *src = reinterpret_cast<const uint4 *>(in + t);
-    uint4 *dst = reinterpret_cast<uint4 *>(out + s);
-    const uint4 lo = src[0], hi = src[1];
-    dst[0] = lo;
-    dst[1] = hi;
-  }
-  if (t == count - 1)
-  {
-    *nkept = (uint64_t) s + k;
-  }
-}
+#include "search_complete.inc"
+#include "search_query.inc"
+#include "mum_workplan.inc"
+#include "mum_filter.inc"
+#include "selfmum_scan.inc"
 
 // ---------------------------------------------------------------------------
 // host side
