@@ -450,3 +450,68 @@ def test_empty_results_leave_no_error_behind(V):
     tiny = V.Index.build(np.array([0, 1], np.uint8), 4, 1)
     assert V.findmaximalrepeats(tiny, 1).count == 0
     assert V.findsupermaximalrepeats(tiny, 1).count == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mum_work_plan_on_hard_batches(V, seed):
+    """the first pass + work plan (offsets that cannot be candidates are not
+    searched) on batches built to stress it: repetitive text (non-unique
+    longest matches), reads with 0..6 substitutions at random and at chosen
+    positions (first and last symbols, just inside and outside the last l
+    symbols), wildcards in reads and text, reads that run into a sequence
+    boundary, random reads; -mum cand and -mum against the oracle, in
+    order"""
+    rng = np.random.default_rng(4000 + seed)
+    m = [100, 60, 150, 100, 254, 33][seed]
+    L = [20, 12, 31, 14, 40, 16][seed]
+    unit = rng.integers(0, 4, 3 * m).astype(np.uint8)
+    seqs = []
+    for s in range(3):
+        t = rng.integers(0, 4, 30000).astype(np.uint8)
+        for r in range(8):
+            p = int(rng.integers(0, 30000 - len(unit)))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 4))):
+                u[int(rng.integers(0, len(u)))] = rng.integers(0, 4)
+            t[p:p + len(u)] = u
+        t[rng.random(30000) < 0.0005] = H.WILDCARD
+        seqs.append(t)
+    tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
+                          for s in seqs])[:-1].astype(np.uint8)
+    nq = 3000
+    qb = np.zeros(nq * m, np.uint8)
+    for i in range(nq):
+        kind = i % 10
+        p = int(rng.integers(0, len(tis) - m))
+        q = tis[p:p + m].copy()
+        q[q == H.SEPARATOR] = rng.integers(0, 4)   # read across a boundary
+        if kind == 9:
+            q = rng.integers(0, 4, m).astype(np.uint8)
+        elif kind == 8:
+            pos = [0, m - 1, m - L, m - L - 1, L - 1, L][i // 10 % 6]
+            q[pos] = (q[pos] + 1) % 4 if q[pos] < 4 else 0
+        else:
+            for e in range(int(rng.integers(0, 7)) if kind < 6 else 0):
+                x = int(rng.integers(0, m))
+                q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4 if q[x] < 4 else 1
+        if i % 97 == 0:
+            q[int(rng.integers(0, m))] = H.WILDCARD
+        qb[i * m:(i + 1) * m] = q
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    hq = H.Queries.uniform(qb, m)
+    gq = V.Queries.from_host(qb, np.arange(nq, dtype=np.uint64) * m,
+                             np.full(nq, m, np.uint64))
+    if L < gi.info().prefixlength:
+        L = gi.info().prefixlength
+    cand = V.findquerymatches(gi, gq, L, mum=True, cand=True)
+    want = H.oracle_querymatches(host, hq, L, mum=True, cand=True, speedup=0)
+    assert len(want) > nq // 4
+    assert np.array_equal(cand.fetch(), want)
+    # the plan really left offsets out
+    assert cand.stats().kernel_searches < nq * (m - L + 1) // 2
+    mum = V.findquerymatches(gi, gq, L, mum=True).fetch()
+    assert np.array_equal(mum, H.oracle_querymatches(host, hq, L, mum=True,
+                                                     speedup=2))
