@@ -442,6 +442,11 @@ typedef struct
 {
   int kind;              /* VSA_SINK_...                                  */
   int palindromic;       /* matches of the reverse-complement pass (-p)   */
+  int selfpalindromic;   /* ... of the index against itself (vmatch -p IDX,
+                            Vmatch/runself.c:127-178): the query set is the
+                            index; of the two mirror images of a match only
+                            the one with the smaller left position is kept
+                            (procfinal.c:159-167)                         */
   uint32_t showmode;     /* VSA_SHOW_... bits                             */
   uint32_t numofchars;   /* alpha.mapsize - 1: E-value match probability  */
   int threads;           /* formatting threads; 0 = one per processor     */

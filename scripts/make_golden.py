@@ -113,6 +113,13 @@ def main():
     record(case, "supermax30", ["-supermax", "-l", "30", "ychrIII.fna"], wd)
     # maximal repeats (Vmengine/vmatfind.c), the default task of vmatch
     record(case, "repeats40", ["-l", "40", "ychrIII.fna"], wd)
+    # palindromic self matches: the reverse complement of the index is
+    # matched against the index (Vmatch/runself.c:127-178)
+    for sp in (0, 2):
+        record(case, "palindromic30_sp%d" % sp,
+               ["-qspeedup", str(sp), "-p", "-l", "30", "ychrIII.fna"], wd)
+    record(case, "repeats_dp40", ["-d", "-p", "-l", "40", "ychrIII.fna"], wd,
+           both=True)
     shutil.rmtree(wd)
 
     # ---- 2. micro: multi-FASTA, wildcards, prefixlength 1 ----------------

@@ -655,6 +655,41 @@ def load_case(case):
     return _cases[case]
 
 
+def index_as_rc_queries(index):
+    """the query set of vmatch -p IDX: every sequence of the index reversed
+    and complemented on its own (copymultiseqRC, readmulti.c:93-125)"""
+    bounds = np.concatenate(([-1], index.ssp.astype(np.int64), [index.n]))
+    sym = index.tis.copy()
+    start, length = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        s, l = int(a) + 1, int(b - a - 1)
+        seg = index.tis[s:s + l][::-1]
+        sym[s:s + l] = np.where(seg >= WILDCARD, seg, 3 - seg)
+        start.append(s)
+        length.append(l)
+    return Queries(sym, start, length)
+
+
+def palindromic_as_ref(index, m):
+    """matches of the reverse complements against the index -> what vmatch
+    -p IDX prints: position flipped back to the forward strand, of the two
+    mirror images the one with the smaller left position
+    (Vmatch/procfinal.c:152-167)"""
+    dt = np.dtype([("length", "<u8"), ("dbseq", "<u8"), ("dbrel", "<u8"),
+                   ("queryseq", "<u8"), ("querystart", "<u8")])
+    bounds = np.concatenate(([-1], index.ssp.astype(np.int64), [index.n]))
+    seqlen = (bounds[1:] - bounds[:-1] - 1).astype(np.uint64)
+    s1, r1 = index.seq_rel(m["dbstart"])
+    q = m["queryseq"].astype(np.int64)
+    r2 = seqlen[q] - (m["querystart"] + m["length"])
+    keep = ~((s1 > m["queryseq"]) | ((s1 == m["queryseq"]) & (r1 > r2)))
+    out = np.zeros(int(keep.sum()), dt)
+    out["length"], out["dbseq"], out["dbrel"] = (m["length"][keep], s1[keep],
+                                                 r1[keep])
+    out["queryseq"], out["querystart"] = m["queryseq"][keep], r2[keep]
+    return out
+
+
 def repeats_as_ref(index, m):
     """self matches (length, start1, start2) of an index without queries ->
     the reference's output tuple"""

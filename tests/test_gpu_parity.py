@@ -37,6 +37,11 @@ def run_gpu(V, case, key, bits=64):
     if key.startswith("supermax"):
         r = V.findsupermaximalrepeats(gi, int(key[len("supermax"):]))
         return H.repeats_as_ref(idx, r.fetch())
+    if key.startswith("palindromic"):
+        rq = H.index_as_rc_queries(idx)
+        L = int(key[len("palindromic"):].partition("_sp")[0])
+        return H.palindromic_as_ref(
+            idx, V.findquerymatches(gi, gpu_queries(V, rq), L).fetch())
     if key.startswith("repeats"):
         r = V.findmaximalrepeats(gi, int(key[len("repeats"):]))
         conv = H.selfmatches_as_ref if idx.hasqueries else H.repeats_as_ref
@@ -68,7 +73,8 @@ def test_gpu_reproduces_reference_output(V, case, key):
     got = run_gpu(V, case, key)
     want = H.expected(case, key)
     assert len(got) == len(want)
-    if key.startswith("mem") and not key.endswith("_sp0"):
+    if (key.startswith("mem") or key.startswith("palindromic")) and \
+            not key.endswith("_sp0"):
         # recorded with the reference's default algorithm 2
         assert np.array_equal(H.sorted_matches(got), H.sorted_matches(want))
     else:

@@ -30,6 +30,12 @@ def run_oracle(case, key):
     if key.startswith("selfmum"):
         L = int(key[len("selfmum"):])
         return H.selfmatches_as_ref(idx, H.oracle_selfmum(idx, L)), None
+    if key.startswith("palindromic"):
+        L = int(key[len("palindromic"):].partition("_sp")[0])
+        sp = int(key.partition("_sp")[2])
+        m = H.oracle_querymatches(idx, H.index_as_rc_queries(idx), L,
+                                  speedup=sp)
+        return H.palindromic_as_ref(idx, m), None
     if key.startswith("repeats"):
         L = int(key[len("repeats"):])
         conv = H.selfmatches_as_ref if idx.hasqueries else H.repeats_as_ref

@@ -65,6 +65,16 @@ def test_sink_prints_what_vmatch_printed(case, key):
                       totalquerylength=idx.n - idx.querysepposition - 1,
                       leastlength=int("".join(
                           ch for ch in key if ch.isdigit())))
+    elif key.startswith("palindromic"):
+        # printed positions are on the forward strand: back to the offset in
+        # the reverse complement the engine reported
+        rq = H.index_as_rc_queries(idx)
+        m = records(idx, exp)
+        m["querystart"] = rq.length[exp["queryseq"].astype(np.int64)] - (
+            exp["querystart"] + exp["length"])
+        sink = V.Sink(V.SINK_QUERY, idx.n, idx.ssp, 4, rq.start, rq.length,
+                      idx.n, leastlength=30, palindromic=True,
+                      selfpalindromic=True)
     elif key.startswith("supermax") or key.startswith("repeats"):
         starts = np.concatenate(([0], idx.ssp + 1)).astype(np.uint64)
         m = records(idx, exp)

@@ -66,7 +66,7 @@ class IndexInfo(C.Structure):
 
 class SinkParams(C.Structure):
     _fields_ = [("kind", C.c_int), ("palindromic", C.c_int),
-                ("showmode", C.c_uint32), ("numofchars", C.c_uint32),
+                ("selfpalindromic", C.c_int), ("showmode", C.c_uint32), ("numofchars", C.c_uint32),
                 ("threads", C.c_int),
                 ("leastlength", C.c_uint64), ("totallength", C.c_uint64),
                 ("numofsequences", C.c_uint64), ("markpos", C.c_void_p),
@@ -494,10 +494,12 @@ class Sink:
     def __init__(self, kind, totallength, markpos, numofchars=4,
                  querystart=None, querylength=None, querytotallength=0,
                  numofquerysequences=0, totalquerylength=0, leastlength=0,
-                 palindromic=False, showmode=0, threads=0):
+                 palindromic=False, showmode=0, threads=0,
+                 selfpalindromic=False):
         self._keep = [np.ascontiguousarray(markpos, np.uint64)]
         p = SinkParams()
         p.kind, p.palindromic = int(kind), int(bool(palindromic))
+        p.selfpalindromic = int(bool(selfpalindromic))
         p.showmode, p.numofchars = int(showmode), int(numofchars)
         p.threads = int(threads)
         p.leastlength, p.totallength = int(leastlength), int(totallength)

@@ -429,6 +429,12 @@ static char *formatmatch(const vsa_sink *s, Fcache *cache,
     if (s->p.palindromic)
     {
       relpos2 = seqlength2 - (relpos2 + length2); /* procfinal.c:152-158 */
+      if (s->p.selfpalindromic &&
+          (seqnum1 > seqnum2 ||
+           (seqnum1 == seqnum2 && position1 - start1 > relpos2)))
+      {
+        return o; /* the mirror image is the one reported, :159-167 */
+      }
     }
     position2 = seqstart2 + relpos2;
   } else
@@ -490,8 +496,11 @@ static char *formatmatch(const vsa_sink *s, Fcache *cache,
     if (isquery)
     {
       multiplier = iscomplete ? (double) s->p.totallength
-                              : (double) s->p.totallength *
-                                    (double) s->qlength[m->queryseq];
+                   : (s->p.palindromic && s->p.selfpalindromic)
+                       ? 0.5 * (double) s->p.totallength *
+                             (double) s->p.querytotallength
+                       : (double) s->p.totallength *
+                             (double) s->qlength[m->queryseq];
     } else if (s->p.totalquerylength > 0)
     {
       multiplier = (double) s->dblen * (double) s->p.totalquerylength;
