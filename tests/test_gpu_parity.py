@@ -522,3 +522,52 @@ def test_mum_work_plan_on_hard_batches(V, seed):
     mum = V.findquerymatches(gi, gq, L, mum=True).fetch()
     assert np.array_equal(mum, H.oracle_querymatches(host, hq, L, mum=True,
                                                      speedup=0))
+
+
+@pytest.mark.parametrize("case", ["micro", "grumbach", "grumbach_all",
+                                  "largepat"])
+def test_wide_device_tables(V, case, monkeypatch):
+    """VSA_FORCE_WIDE=1: the 64-bit instantiations of every kernel (what an
+    index beyond 2^32 positions uses) on the golden cases"""
+    monkeypatch.setenv("VSA_FORCE_WIDE", "1")
+    idx, q = H.load_case(case)
+    i = idx.as_width(64)
+    gi = V.Index.from_tables(i.n, i.prefixlength, i.numofchars, i.tis, i.suf,
+                             i.lcp, i.llv, i.bck, i.bwt, i.querysepposition,
+                             i.hasqueries)
+    assert gi.info().device_integersize == 64
+    for key in sorted(M[case]["runs"]):
+        run = M[case]["runs"][key]
+        if "strands" in run or key.endswith("_short") or \
+                key.startswith("approx_"):
+            continue
+        want = H.expected(case, key)
+        if key.startswith("selfmum"):
+            got = H.selfmatches_as_ref(idx, V.findmaximaluniquematches(
+                gi, int(key[len("selfmum"):])).fetch())
+        elif key.startswith("supermax"):
+            got = H.repeats_as_ref(idx, V.findsupermaximalrepeats(
+                gi, int(key[len("supermax"):])).fetch())
+        elif key.startswith("repeats"):
+            conv = (H.selfmatches_as_ref if idx.hasqueries
+                    else H.repeats_as_ref)
+            got = conv(idx, V.findmaximalrepeats(
+                gi, int(key[len("repeats"):])).fetch())
+        elif key.startswith("palindromic"):
+            continue
+        else:
+            gq = gpu_queries(V, q)
+            if key.startswith("complete"):
+                got = H.matches_as_ref(idx,
+                                       V.findcompletematches(gi, gq).fetch())
+            else:
+                name = key.partition("_sp")[0]
+                L = int("".join(ch for ch in name if ch.isdigit()))
+                got = H.matches_as_ref(idx, V.findquerymatches(
+                    gi, gq, L, mum=name.startswith("mum"),
+                    cand="cand" in name).fetch())
+        if key.startswith("mem") and not key.endswith("_sp0"):
+            assert np.array_equal(H.sorted_matches(got),
+                                  H.sorted_matches(want)), (case, key)
+        else:
+            assert np.array_equal(got, want), (case, key)

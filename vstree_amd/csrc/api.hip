@@ -172,6 +172,15 @@ int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
   ix->nllv = nllv;
   ix->numofcodes = powu64(numofchars, pl);
   ix->isize = (n + 1 <= 0xFFFFFFFFull) ? 4 : 8;
+  {
+    // VSA_FORCE_WIDE=1: 64-bit device tables whatever the length (tests of
+    // the wide instantiations on small inputs)
+    const char *wide = getenv("VSA_FORCE_WIDE");
+    if (wide != nullptr && strcmp(wide, "1") == 0)
+    {
+      ix->isize = 8;
+    }
+  }
   *out = ix;
   VSA_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
   const uint64_t tisbytes = VSA_TIS_FRONTPAD + n + VSA_TIS_BACKPAD,
