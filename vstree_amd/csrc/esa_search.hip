@@ -1,22 +1,37 @@
-// Search kernels of the Vmengine query path on MI355X and their host-side
-// pipelines.  Kernel inventory (DESIGN.md has the byte budgets):
+// The search engine on MI355X: kernels (in the .inc files below, one
+// translation unit) and their host-side pipelines.  DESIGN.md has the byte
+// budgets and the measurements.
 //
-//   K1  k_complete_search   one work-item per query: bucket -> lcp-aware
-//                           binary search -> lcptab widening; writes the
-//                           suffix-array interval [left, left+count)
-//       k_complete_expand   one work-item per match (load-balanced over the
-//                           scanned counts): suf[left+k] -> vsa_match
-//   K2  k_query_search      one work-item per query suffix: bucket -> binary
-//                           search -> MEM enumeration or MUM-candidate test;
-//                           wavefront-aggregated append, then a stable radix
-//                           sort by work-item number restores reference order
-//   K4  k_mum_*             candidates sorted by (dbstart asc, length desc),
-//                           prefix-max scan, flag, compact
-//                           (kurtz/cleanMUMcand.c:55-118)
-//   K3  k_selfmum_peaks     streaming scan over lcptab for indexes that hold
-//       k_selfmum_emit      their queries (Vmengine/fmumself.c:10-66)
+//   search_complete.inc  K1  k_complete_search   one work-item per query:
+//                            locate -> lcptab widening -> suffix-array
+//                            interval [left, left+count)
+//                            k_complete_expand   one work-item per match
+//   search_query.inc     K2  k_query_search      one work-item per (query,
+//                            offset): locate -> MEM enumeration or
+//                            MUM-candidate test; wavefront-aggregated append
+//                            into sharded regions, compaction, stable radix
+//                            sort by work-item number = reference order
+//   mum_workplan.inc     K2a k_mum_first / k_mum_plan / k_expand_plan (and
+//                            the older k_mum_anchor): which offsets of a
+//                            query can be MUM candidates at all
+//   mum_filter.inc       K4  candidates sorted by (dbstart asc, length desc),
+//                            prefix-max scan, flag, ordered compaction
+//                            (kurtz/cleanMUMcand.c:55-118)
+//   selfmum_scan.inc     K3  k_selfmum_peaks / k_selfmum_emit: streaming scan
+//                            over lcptab + bwttab for indexes that hold
+//                            their queries (Vmengine/fmumself.c:10-66)
+//   approx_search.inc    A   approximate complete matches (-complete -e/-h)
+//   selfmatch_search.inc R,S maximal and supermaximal repeats of the index
 //
-// rocPRIM supplies radix sort / scan / select / reduce only.
+// rocPRIM supplies radix sort / scan / reduce only.
+//
+// Experiment switches (environment, read when an index is created):
+//   VSA_TUNE bit 0  nontemporal probes in the deep locate
+//            bit 1  no MUM work reduction at all (every offset is searched)
+//            bit 2  no work plan (anchor pass only)
+//            bit 3  anchor pass + plan instead of first pass + plan
+//            bits 8..19  workgroup size of K2 (64, 128, 256, 512)
+//   VSA_NO_ESA8=1, VSA_DEEP_PREFIX=D   the keyed search array off / its depth
 #include <cstring>
 #include <algorithm>
 #include "esa_device.hpp"

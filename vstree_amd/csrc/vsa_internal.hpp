@@ -63,7 +63,7 @@ struct DevIndex
   const uint32_t *bck2;
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars, D;
-  uint32_t tune; // experiment switches (VSA_TUNE): bit0 = nontemporal probes
+  uint32_t tune; // experiment switches (VSA_TUNE), see esa_search.hip
 };
 
 #define VSA_KEYSYMS 11u
