@@ -458,7 +458,7 @@ def test_empty_results_leave_no_error_behind(V):
     assert V.findsupermaximalrepeats(tiny, 1).count == 0
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(7))
 def test_mum_work_plan_on_hard_batches(V, seed):
     """the first pass + work plan (offsets that cannot be candidates are not
     searched) on batches built to stress it: repetitive text (non-unique
@@ -468,8 +468,8 @@ def test_mum_work_plan_on_hard_batches(V, seed):
     boundary, random reads; -mum cand and -mum against the oracle, in
     order"""
     rng = np.random.default_rng(4000 + seed)
-    m = [100, 60, 150, 100, 254, 33][seed]
-    L = [20, 12, 31, 14, 40, 16][seed]
+    m = [100, 60, 150, 100, 254, 33, 300][seed]   # 300: anchor pass only
+    L = [20, 12, 31, 14, 40, 16, 25][seed]
     unit = rng.integers(0, 4, 3 * m).astype(np.uint8)
     seqs = []
     for s in range(3):
@@ -571,3 +571,25 @@ def test_wide_device_tables(V, case, monkeypatch):
                                   H.sorted_matches(want)), (case, key)
         else:
             assert np.array_equal(got, want), (case, key)
+
+
+@pytest.mark.parametrize("tune", [2, 4, 8])
+def test_older_work_reduction_paths_still_agree(V, tune, monkeypatch):
+    """VSA_TUNE bits 1-3 switch the first pass / the plan / all work
+    reduction off (esa_search.hip): the lists must not change"""
+    monkeypatch.setenv("VSA_TUNE", str(tune))
+    idx, q = H.load_case("c1")
+    i = idx.as_width(64)
+    gi = V.Index.from_tables(i.n, i.prefixlength, i.numofchars, i.tis, i.suf,
+                             i.lcp, i.llv, i.bck, i.bwt, i.querysepposition,
+                             i.hasqueries)
+    gq = gpu_queries(V, q)
+    r = V.findquerymatches(gi, gq, 20, mum=True, cand=True)
+    assert np.array_equal(H.matches_as_ref(idx, r.fetch()),
+                          H.expected("c1", "mumcand20"))
+    full = q.nq * (100 - 20 + 1)
+    assert (r.stats().kernel_searches == full) == (tune == 2)
+    assert np.array_equal(
+        H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
+                                                 mum=True).fetch()),
+        H.expected("c1", "mum20"))
