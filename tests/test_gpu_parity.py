@@ -468,7 +468,7 @@ def test_mum_work_plan_on_hard_batches(V, seed):
     boundary, random reads; -mum cand and -mum against the oracle, in
     order"""
     rng = np.random.default_rng(4000 + seed)
-    m = [100, 60, 150, 100, 254, 33, 300][seed]   # 300: anchor pass only
+    m = [100, 60, 150, 100, 254, 33, 300][seed]
     L = [20, 12, 31, 14, 40, 16, 25][seed]
     unit = rng.integers(0, 4, 3 * m).astype(np.uint8)
     seqs = []
@@ -517,7 +517,7 @@ def test_mum_work_plan_on_hard_batches(V, seed):
     assert len(want) > nq // 4
     assert np.array_equal(cand.fetch(), want)
     # the plan really left offsets out (short reads leave little to skip)
-    if m >= 4 * L and m < 255:
+    if m >= 4 * L:
         assert cand.stats().kernel_searches < nq * (m - L + 1) // 2
     mum = V.findquerymatches(gi, gq, L, mum=True).fetch()
     assert np.array_equal(mum, H.oracle_querymatches(host, hq, L, mum=True,
@@ -593,3 +593,28 @@ def test_older_work_reduction_paths_still_agree(V, tune, monkeypatch):
         H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
                                                  mum=True).fetch()),
         H.expected("c1", "mum20"))
+
+
+def test_long_reads_on_a_text_whose_largest_suffixes_share_255_symbols(V):
+    """the one situation in which the reference's uniqueness test for
+    lcp >= 255 (fquery.c:352) accepts a repeated match: the text ends in a
+    long run of its largest symbol.  The work reduction steps aside for long
+    reads there; lists equal the oracle, which restates the quirk."""
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 4, 20000).astype(np.uint8)
+    g[-600:] = 3
+    gi = V.Index.build(g, 4, 0)
+    t = gi.download()
+    host = H.Index(len(g), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    m, nq = 400, 40
+    qb = np.concatenate([g[len(g) - m - 7 * i:len(g) - 7 * i] if i else g[-m:]
+                         for i in range(nq)]).astype(np.uint8)
+    hq = H.Queries.uniform(qb, m)
+    gq = V.Queries.from_host(qb, np.arange(nq, dtype=np.uint64) * m,
+                             np.full(nq, m, np.uint64))
+    for L in (20, 260):
+        got = V.findquerymatches(gi, gq, L, mum=True, cand=True).fetch()
+        want = H.oracle_querymatches(host, hq, L, mum=True, cand=True,
+                                     speedup=0)
+        assert np.array_equal(got, want)

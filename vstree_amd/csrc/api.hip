@@ -172,6 +172,7 @@ int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
   ix->nllv = nllv;
   ix->numofcodes = powu64(numofchars, pl);
   ix->isize = (n + 1 <= 0xFFFFFFFFull) ? 4 : 8;
+  ix->lcpquirk = -1;
   {
     // VSA_FORCE_WIDE=1: 64-bit device tables whatever the length (tests of
     // the wide instantiations on small inputs)

@@ -582,8 +582,20 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
+  if (domum && qs.uniformlen >= 255 && index->lcpquirk < 0)
+  {
+    uint8_t b = 0;
+    if (index->n >= 2)
+    {
+      VSA_HIP(hipMemcpyAsync(&b, index->lcp + index->n - 1, 1,
+                             hipMemcpyDeviceToHost, stream));
+      VSA_HIP(hipStreamSynchronize(stream));
+    }
+    index->lcpquirk = (b == 255) ? 1 : 0;
+  }
   if (domum && qs.uniformlen != 0 && perquery > 1 &&
-      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0)
+      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0 &&
+      !(qs.uniformlen >= 255 && index->lcpquirk != 0))
   {
     const uint64_t nq = queries->nq;
     Timer tanchor(stream);
@@ -593,10 +605,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     tanchor.start();
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
-    // work plan (see k_mum_plan); the quirk of the reference's uniqueness
-    // test for lcp >= 255 (fquery.c:352) keeps longer queries out
-    const bool planned = qs.uniformlen < 255 && perquery < 0xFFFFu &&
-                         (index->tune & 4u) == 0;
+    // work plan (see k_mum_plan).  All of the work reduction rests on "a
+    // match that is not unique is no candidate"; the reference's test for
+    // lcp >= 255 (fquery.c:352) breaks that rule in one situation, which one
+    // byte of lcptab rules out (see vsa_index::lcpquirk)
+    const bool planned = perquery < 0xFFFFu && (index->tune & 4u) == 0;
     // planned batches start with offset 0 (k_mum_first), the others with the
     // anchor pass from the last offset
     firstpass = planned && (index->tune & 8u) == 0;

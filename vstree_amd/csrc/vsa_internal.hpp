@@ -87,6 +87,10 @@ struct vsa_index
   uint64_t querysepposition;
   int hasindexedqueries;
   uint64_t device_bytes;
+  // 1: the two largest suffixes share >= 255 symbols, the one situation in
+  // which the reference's uniqueness test for lcp >= 255 (fquery.c:352) can
+  // call a repeated match unique; 0: cannot happen; -1: not looked at yet
+  mutable int lcpquirk;
 
   template <typename IDX>
   DevIndex<IDX> view() const
