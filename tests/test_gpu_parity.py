@@ -618,3 +618,53 @@ def test_long_reads_on_a_text_whose_largest_suffixes_share_255_symbols(V):
         want = H.oracle_querymatches(host, hq, L, mum=True, cand=True,
                                      speedup=0)
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_mum_work_plan_on_ragged_batches(V, seed):
+    """reads of different lengths (some shorter than the search length, one
+    empty) take the first pass + work plan with per-query geometry"""
+    rng = np.random.default_rng(7000 + seed)
+    L = [20, 14, 30][seed]
+    unit = rng.integers(0, 4, 400).astype(np.uint8)
+    seqs = []
+    for s in range(2):
+        t = rng.integers(0, 4, 30000).astype(np.uint8)
+        for r in range(6):
+            p = int(rng.integers(0, 30000 - 400))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 4))):
+                u[int(rng.integers(0, 400))] = rng.integers(0, 4)
+            t[p:p + 400] = u
+        t[rng.random(30000) < 0.0005] = H.WILDCARD
+        seqs.append(t)
+    tis = np.concatenate([seqs[0], [H.SEPARATOR], seqs[1]]).astype(np.uint8)
+    reads = []
+    for i in range(2500):
+        m = int(rng.integers(max(1, L - 6), 260))
+        if i == 17:
+            m = 0
+        p = int(rng.integers(0, len(tis) - 300))
+        q = tis[p:p + m].copy()
+        q[q == H.SEPARATOR] = rng.integers(0, 4)
+        for e in range(int(rng.integers(0, 5)) if i % 3 else 0):
+            if m:
+                x = int(rng.integers(0, m))
+                q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4 if q[x] < 4 else 2
+        reads.append(q)
+    hq = H.Queries.from_list(reads)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    L = max(L, gi.info().prefixlength)
+    gq = gpu_queries(V, hq)
+    cand = V.findquerymatches(gi, gq, L, mum=True, cand=True)
+    want = H.oracle_querymatches(host, hq, L, mum=True, cand=True, speedup=0)
+    assert len(want) > 500
+    assert np.array_equal(cand.fetch(), want)
+    full = int(np.maximum(hq.length.astype(np.int64) - L + 1, 0).sum())
+    assert cand.stats().kernel_searches < full // 2
+    assert np.array_equal(
+        V.findquerymatches(gi, gq, L, mum=True).fetch(),
+        H.oracle_querymatches(host, hq, L, mum=True, speedup=0))

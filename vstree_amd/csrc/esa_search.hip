@@ -582,7 +582,12 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
-  if (domum && qs.uniformlen >= 255 && index->lcpquirk < 0)
+  // ragged batches take the same route with per-query geometry
+  const uint64_t maxoffsets =
+      (queries->maxlength >= searchlength)
+          ? queries->maxlength - searchlength + 1
+          : 0;
+  if (domum && queries->maxlength >= 255 && index->lcpquirk < 0)
   {
     uint8_t b = 0;
     if (index->n >= 2)
@@ -593,9 +598,18 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     index->lcpquirk = (b == 255) ? 1 : 0;
   }
-  if (domum && qs.uniformlen != 0 && perquery > 1 &&
-      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0 &&
-      !(qs.uniformlen >= 255 && index->lcpquirk != 0))
+  // work plan (see k_mum_plan).  All of the work reduction rests on "a match
+  // that is not unique is no candidate"; the reference's test for lcp >= 255
+  // (fquery.c:352) breaks that rule in one situation, which one byte of
+  // lcptab rules out (see vsa_index::lcpquirk)
+  const bool planned = maxoffsets < 0xFFFFu && (index->tune & 4u) == 0;
+  // planned batches start with offset 0 (k_mum_first); the anchor pass from
+  // the last offset serves batches of equal-length queries only
+  firstpass = planned && (index->tune & 8u) == 0;
+  if (domum && maxoffsets > 1 && queries->nq < 0xFFFFFFFFull &&
+      (index->tune & 2u) == 0 &&
+      !(queries->maxlength >= 255 && index->lcpquirk != 0) &&
+      (qs.uniformlen != 0 || firstpass))
   {
     const uint64_t nq = queries->nq;
     Timer tanchor(stream);
@@ -605,14 +619,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     tanchor.start();
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
-    // work plan (see k_mum_plan).  All of the work reduction rests on "a
-    // match that is not unique is no candidate"; the reference's test for
-    // lcp >= 255 (fquery.c:352) breaks that rule in one situation, which one
-    // byte of lcptab rules out (see vsa_index::lcpquirk)
-    const bool planned = perquery < 0xFFFFu && (index->tune & 4u) == 0;
-    // planned batches start with offset 0 (k_mum_first), the others with the
-    // anchor pass from the last offset
-    firstpass = planned && (index->tune & 8u) == 0;
     if (firstpass)
     {
       if (wfirste.alloc(nq * 4) || wfmlen.alloc(nq * 4) ||
@@ -741,6 +747,10 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     dwlq = wlq.as<uint32_t>();
     dwloff = wloff.as<uint32_t>();
     res->stats.searches = nwork + nq + plansearches;
+  }
+  if (dwlq == nullptr)
+  {
+    firstpass = false; // the work reduction was not entered
   }
   std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
   DevBuf doff, rawout, rawkeys;
@@ -892,7 +902,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     {
       k_append_first<<<gridfor(queries->nq), VSA_BLOCK, 0, stream>>>(
           wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
-          wfslot.as<uint32_t>(), queries->nq, perquery, qs.seqoffset, needed,
+          wfslot.as<uint32_t>(), queries->nq, perquery, dbase, qs.seqoffset,
+          needed,
           out.as<vsa_match>(), keys.as<uint64_t>());
       VSA_HIP(hipGetLastError());
     }
