@@ -109,14 +109,17 @@ __device__ __forceinline__ int vsa_compare(const DevIndex<IDX> &ix,
 // The same comparison, 32 symbols per round trip: used where all lanes of a
 // wavefront extend a long match at the same time, so that the number of
 // dependent memory steps, not the number of loads, sets the pace.
-template <typename IDX>
+// AHEAD: 32-symbol pieces fetched per round trip.  1 suits searches that
+// usually stop within the first piece; the first pass of a MUM batch, where
+// most reads match over their whole length, asks for 3 so that a 100 bp read
+// is compared in one round trip instead of three.
+template <typename IDX, int AHEAD = 1>
 __device__ __forceinline__ int vsa_compare32(const DevIndex<IDX> &ix,
                                              uint64_t sufstart,
                                              const uint8_t *query,
                                              uint32_t querylen,
                                              uint32_t &lcplen)
 {
-  const uint8_t *t = ix.tis + sufstart;
   uint32_t l = lcplen;
 
   for (;;)
@@ -126,44 +129,80 @@ __device__ __forceinline__ int vsa_compare32(const DevIndex<IDX> &ix,
       lcplen = querylen;
       return 0;
     }
-    uint64_t a[4], b[4], m[4];
+    uint64_t a[AHEAD][4], b[AHEAD][4];
+#pragma unroll
+    for (int r = 0; r < AHEAD; r++)
     {
-      const vsa_u128 qa = vsa_load16(query + l), qb = vsa_load16(query + l + 16),
-                     ta = vsa_load16(t + l), tb = vsa_load16(t + l + 16);
-      a[0] = qa.lo;
-      a[1] = qa.hi;
-      a[2] = qb.lo;
-      a[3] = qb.hi;
-      b[0] = ta.lo;
-      b[1] = ta.hi;
-      b[2] = tb.lo;
-      b[3] = tb.hi;
+      // pieces behind the end of the query are not fetched; pieces behind
+      // the end of the text are never looked at (the padding behind the text
+      // makes an earlier piece mismatch): keep their loads inside it
+      const uint32_t off = l + 32u * (uint32_t) r;
+      if (r == 0 || off < querylen)
+      {
+        uint64_t tpos = sufstart + off;
+        if (r > 0 && tpos > ix.n + 32)
+        {
+          tpos = ix.n + 32;
+        }
+        const vsa_u128 qa = vsa_load16(query + off),
+                       qb = vsa_load16(query + off + 16),
+                       ta = vsa_load16(ix.tis + tpos),
+                       tb = vsa_load16(ix.tis + tpos + 16);
+        a[r][0] = qa.lo;
+        a[r][1] = qa.hi;
+        a[r][2] = qb.lo;
+        a[r][3] = qb.hi;
+        b[r][0] = ta.lo;
+        b[r][1] = ta.hi;
+        b[r][2] = tb.lo;
+        b[r][3] = tb.hi;
+      } else
+      {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          a[r][k] = b[r][k] = 0;
+        }
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int r = 0; r < AHEAD; r++)
     {
-      m[k] = (a[k] ^ b[k]) | vsa_specialmask(a[k]) | vsa_specialmask(b[k]);
+      uint64_t m[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        m[k] = (a[r][k] ^ b[r][k]) | vsa_specialmask(a[r][k]) |
+               vsa_specialmask(b[r][k]);
+      }
+      if ((m[0] | m[1] | m[2] | m[3]) == 0)
+      {
+        l += 32;
+        if (l >= querylen)
+        {
+          lcplen = querylen;
+          return 0;
+        }
+        continue;
+      }
+      int k = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
+      const uint64_t mm = m[0] ? m[0] : (m[1] ? m[1] : (m[2] ? m[2] : m[3]));
+      const uint64_t aa = m[0] ? a[r][0]
+                               : (m[1] ? a[r][1] : (m[2] ? a[r][2] : a[r][3]));
+      const uint64_t bb = m[0] ? b[r][0]
+                               : (m[1] ? b[r][1] : (m[2] ? b[r][2] : b[r][3]));
+      const uint32_t j = (uint32_t) __builtin_ctzll(mm) >> 3;
+      l += 8 * k + j;
+      if (l >= querylen)
+      {
+        lcplen = querylen;
+        return 0;
+      }
+      lcplen = l;
+      const int qa = (int) ((aa >> (8 * j)) & 0xFF),
+                tb = (int) ((bb >> (8 * j)) & 0xFF);
+      return (qa == tb) ? -1 : qa - tb;
     }
-    if ((m[0] | m[1] | m[2] | m[3]) == 0)
-    {
-      l += 32;
-      continue;
-    }
-    int k = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
-    const uint64_t mm = m[0] ? m[0] : (m[1] ? m[1] : (m[2] ? m[2] : m[3]));
-    const uint64_t aa = m[0] ? a[0] : (m[1] ? a[1] : (m[2] ? a[2] : a[3]));
-    const uint64_t bb = m[0] ? b[0] : (m[1] ? b[1] : (m[2] ? b[2] : b[3]));
-    const uint32_t j = (uint32_t) __builtin_ctzll(mm) >> 3;
-    l += 8 * k + j;
-    if (l >= querylen)
-    {
-      lcplen = querylen;
-      return 0;
-    }
-    lcplen = l;
-    const int qa = (int) ((aa >> (8 * j)) & 0xFF),
-              tb = (int) ((bb >> (8 * j)) & 0xFF);
-    return (qa == tb) ? -1 : qa - tb;
   }
 }
 
@@ -450,11 +489,13 @@ struct DeepHit
   uint8_t leftsym;  // tis[suf[w]-1] (separator if suf[w] = 0)
 };
 
+template <int AHEAD = 1>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
                 uint64_t &w, DeepHit &hit)
 {
+  // AHEAD: see vsa_compare32
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
@@ -672,7 +713,8 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   if (extend)
   {
     uint32_t lcplen = maxlcp;
-    (void) vsa_compare32(ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
+    (void) vsa_compare32<uint32_t, AHEAD>(ix, esucc & 0xFFFFFFFFull, query,
+                                          querylen, lcplen);
     maxlcp = lcplen;
   }
   return state;
