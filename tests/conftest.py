@@ -1,4 +1,5 @@
 import os
+import shutil
 import sys
 
 import pytest
@@ -12,6 +13,19 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def pytest_configure(config):
     config.addinivalue_line(
         "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """A fresh checkout has no built libraries (they are git-ignored): build
+    the product library once, as __graft_entry__.build() does.  Nothing
+    happens when it is there already (e.g. on the GPU box, where it arrives
+    with the snapshot)."""
+    import subprocess
+    lib = os.path.join(ROOT, "vstree_amd", "libvstree_amd.so")
+    if not os.path.exists(lib) and shutil.which("hipcc"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "vstree_amd",
+                                                          "csrc"), "-j8"],
+                              stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
