@@ -152,21 +152,22 @@ def main():
                       s.kernel_searches)
             r.close()
             return
-        # phase 1: candidates of this rank's queries (no communication)
-        r = V.findquerymatches(index, queries, L, mum=True, cand=True)
+        # phase 1: candidates of this rank's queries (no communication), in
+        # the order the kernel left them, grouped by the rank that filters
+        # their range of the index
+        r = V.findmumcandidates(index, queries, L, ordered=False)
         s = r.stats()
         kernel_ms.append(s.search_kernel_ms)
-        mine = torch.zeros(max(r.count, 1) * 4, dtype=torch.int64,
+        mine = torch.empty(max(r.count, 1) * 4, dtype=torch.int64,
                            device="cuda")[:r.count * 4]
-        r.copy_device(C.c_void_p(mine.data_ptr()), r.count)
+        send = r.partition(world, n, C.c_void_p(mine.data_ptr()))
         r.close()
         cdev = "cuda"
         if a.rehearse_on_one_gpu:
             mine, cdev = mine.cpu(), "cpu"
 
-        # phase 2: the one exchange step -- candidates are range-partitioned
-        # by dbstart over the ranks (RCCL all-to-all), every rank runs the
-        # uniqueness filter on its range with the carry of the lower ranges
+        # phase 2: the one exchange step (RCCL all-to-all) -- every rank runs
+        # the uniqueness filter on its range with the carry of the lower ones
         def filter_fn(part, carry):
             part = part.cuda().contiguous()
             res = V.mumuniqueinquery_range(C.c_void_p(part.data_ptr()),
@@ -175,8 +176,8 @@ def main():
             res.close()
             return st.count, st.sumlength
 
-        nmum, sumlen, ncand = S.partitioned_mum_filter(dist, torch, mine, n,
-                                                       cdev, filter_fn)
+        nmum, sumlen, ncand = S.partitioned_mum_filter_presorted(
+            dist, torch, mine, send, cdev, filter_fn)
         # final reduction of the remaining match counters
         searches, ksearches = S.all_reduce_counters(
             dist, torch, [s.searches, s.kernel_searches], cdev)

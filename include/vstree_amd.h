@@ -232,6 +232,29 @@ int vsa_findcompletematches(const vsa_index *index,
                             const vsa_queries *queries, vsa_result **result);
 
 /*
+  The MUM candidates of a batch (vmatch -mum cand -l L), in reference order or
+  -- ordered = 0 -- as the search kernel left them, for callers that hand
+  them to a filter which sorts them anyway: the multi-GPU form of vmatch -mum
+  (kurtz/cleanMUMcand.c:55-118 range-partitioned over the ranks, DESIGN.md
+  section 6).
+*/
+int vsa_findmumcandidates(const vsa_index *index, const vsa_queries *queries,
+                          uint64_t searchlength, int ordered,
+                          vsa_result **result);
+
+/*
+  The records of a result grouped by the range of the index their dbstart
+  falls into -- part p = floor(dbstart * nparts / (totallength + 1)), equal
+  dbstarts in the same part -- written to device_matches (room for
+  vsa_result_count records) part by part; counts[p] (host, nparts entries) =
+  records of part p.  The send buffer and the split sizes of the all-to-all
+  that brings every candidate to the rank filtering its range.
+*/
+int vsa_result_partition(const vsa_result *result, uint32_t nparts,
+                         uint64_t totallength, void *device_matches,
+                         uint64_t *counts);
+
+/*
   findcompletematches for approximate matching on the index, vmatch
   -complete -e K | -h K -q Q IDX: decidefcm -> findedistcompletematchesindex
   / findhammingcompletematchesindex (Vmengine/fcomplete.c:140-261) ->

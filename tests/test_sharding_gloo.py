@@ -58,6 +58,16 @@ def _worker(rank, world, port, outdir):
     pn, ps, pc = S.partitioned_mum_filter(dist, torch, local, idx.n, "cpu",
                                           range_filter_fn)
     assert (pn, ps, pc) == (nmum, sumlen, ncand)
+    # the form bench.py uses: candidates in ANY order, grouped by receiving
+    # rank beforehand (what vsa_result_partition does on the GPU)
+    shuffled = cand[np.random.default_rng(rank).permutation(len(cand))]
+    dest = (shuffled["dbstart"] * np.uint64(world)) // np.uint64(idx.n + 1)
+    grouped = shuffled[np.argsort(dest, kind="stable")]
+    send = np.bincount(dest.astype(np.int64), minlength=world)
+    qn, qs_, qc = S.partitioned_mum_filter_presorted(
+        dist, torch, S.matches_to_tensor(torch, grouped), send, "cpu",
+        range_filter_fn)
+    assert (qn, qs_, qc) == (nmum, sumlen, ncand)
     pparts, _ = S.all_gather_matches(
         dist, torch, S.matches_to_tensor(torch, result["mymums"]), "cpu")
     totals = S.all_reduce_counters(dist, torch,

@@ -138,6 +138,8 @@ def _load():
         "vsa_findapproxcompletematches_cb": (I, [V, V, I, U64, I,
                                                  PROCESSMATCH, V]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
+        "vsa_findmumcandidates": (I, [V, V, U64, I, PP]),
+        "vsa_result_partition": (I, [V, U32, U64, V, V]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
         "vsa_findmaximalrepeats": (I, [V, U64, PP]),
         "vsa_findmaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
@@ -337,6 +339,15 @@ class Result:
     def copy_device(self, device_ptr, capacity):
         _check(lib.vsa_result_copy_device(self._h, device_ptr, capacity))
 
+    def partition(self, nparts, totallength, device_ptr):
+        """records grouped by the index range of their dbstart, written to
+        device_ptr; -> number of records per part"""
+        counts = np.zeros(nparts, np.uint64)
+        _check(lib.vsa_result_partition(self._h, int(nparts),
+                                        int(totallength), device_ptr,
+                                        _ptr(counts)))
+        return counts
+
     def fetch(self):
         n = self.count
         out = np.zeros(n, MATCH_DTYPE)
@@ -393,6 +404,15 @@ def findquerymatches(index, queries, searchlength, mum=False, cand=False):
     _check(lib.vsa_findquerymatches(index._h, queries._h, int(mum),
                                     int(cand), int(searchlength),
                                     C.byref(h)))
+    return Result(h)
+
+
+def findmumcandidates(index, queries, searchlength, ordered=True):
+    """vmatch -mum cand; ordered=False: as the kernel left them (for a
+    filter that sorts them anyway)"""
+    h = C.c_void_p()
+    _check(lib.vsa_findmumcandidates(index._h, queries._h, int(searchlength),
+                                     int(ordered), C.byref(h)))
     return Result(h)
 
 

@@ -523,7 +523,8 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
 
 template <typename IDX>
 int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
-              bool domumcand, uint32_t searchlength, vsa_result *res)
+              bool domumcand, uint32_t searchlength, vsa_result *res,
+              bool ordered = true)
 {
   hipStream_t stream = index->stream;
   Timer tall(stream), tsearch(stream);
@@ -920,6 +921,12 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     res->count = nm;
     res->matches = (vsa_match *) mums.release();
+  } else if (needed > 0 && !ordered && domum)
+  {
+    // candidates for a filter that sorts them anyway (multi-GPU -mum): as
+    // they lie
+    res->count = needed;
+    res->matches = (vsa_match *) out.release();
   } else if (needed > 0)
   {
     // reference order = work-item order; appends of one work-item are
@@ -1264,6 +1271,162 @@ extern "C" int vsa_findcompletematches(const vsa_index *index,
               (unsigned long) index->pl);
     return -2;
   }
+  return 0;
+}
+
+extern "C" int vsa_findmumcandidates(const vsa_index *index,
+                                     const vsa_queries *queries,
+                                     uint64_t searchlength, int ordered,
+                                     vsa_result **result)
+{
+  if (ordered)
+  {
+    return vsa_findquerymatches(index, queries, 1, 1, searchlength, result);
+  }
+  if (index == nullptr || queries == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findmumcandidates: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (index->bck == nullptr)
+  {
+    VSA_ERROR("table bck is not loaded");
+    return -3;
+  }
+  if (searchlength < index->pl || searchlength > 0xFFFFFFF0ull)
+  {
+    // Vmengine/fquery.c:440-446
+    VSA_ERROR("searchlength=%lu must be >= %lu=prefixlen",
+              (unsigned long) searchlength, (unsigned long) index->pl);
+    return -2;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc =
+      (index->isize == 4)
+          ? run_query<uint32_t>(index, queries, true, true,
+                                (uint32_t) searchlength, res, false)
+          : run_query<uint64_t>(index, queries, true, true,
+                                (uint32_t) searchlength, res, false);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
+}
+
+// records of a result by the range of the index their dbstart falls into:
+// part p = floor(dbstart * nparts / (totallength + 1))
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_partition_keys(const vsa_match *__restrict__ m, uint64_t n,
+                 uint32_t nparts, uint64_t totallength,
+                 uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+                 unsigned long long *__restrict__ counts)
+{
+  __shared__ unsigned int hist[256];
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (threadIdx.x < 256)
+  {
+    hist[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (t < n)
+  {
+    const uint32_t p =
+        (uint32_t) ((m[t].dbstart * nparts) / (totallength + 1));
+    key[t] = p;
+    idx[t] = (uint32_t) t;
+    atomicAdd(&hist[p], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nparts && hist[threadIdx.x] != 0)
+  {
+    atomicAdd(counts + threadIdx.x, (unsigned long long) hist[threadIdx.x]);
+  }
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_partition_gather(const vsa_match *__restrict__ m,
+                   const uint32_t *__restrict__ idx, uint64_t n,
+                   vsa_match *__restrict__ out)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t < n)
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(m + idx[t]);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + t);
+    const uint4 lo = src[0], hi = src[1];
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+}
+
+extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
+                                    uint64_t totallength,
+                                    void *device_matches, uint64_t *counts)
+{
+  if (result == nullptr || counts == nullptr || nparts == 0 ||
+      nparts > 256 || (result->count > 0 && device_matches == nullptr))
+  {
+    VSA_ERROR("vsa_result_partition: bad argument (1..256 parts)");
+    return -1;
+  }
+  for (uint32_t p = 0; p < nparts; p++)
+  {
+    counts[p] = 0;
+  }
+  const uint64_t n = result->count;
+  if (n == 0)
+  {
+    return 0;
+  }
+  if (n >= 0xFFFFFFFFull)
+  {
+    VSA_ERROR("vsa_result_partition: more than 2^32 records");
+    return -3;
+  }
+  if (vsa_set_device(result->device) != 0)
+  {
+    return -100;
+  }
+  hipStream_t stream = nullptr;
+  DevBuf key, key2, idx, idx2, dcounts, temp;
+  size_t tb = 0;
+  if (key.alloc(n * 4) || key2.alloc(n * 4) || idx.alloc(n * 4) ||
+      idx2.alloc(n * 4) || dcounts.alloc(256 * 8))
+  {
+    return -100;
+  }
+  VSA_HIP(hipMemsetAsync(dcounts.p, 0, 256 * 8, stream));
+  k_partition_keys<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+      result->matches, n, nparts, totallength, key.as<uint32_t>(),
+      idx.as<uint32_t>(), dcounts.as<unsigned long long>());
+  VSA_HIP(hipGetLastError());
+  const unsigned int bits = bitsfor(nparts - 1);
+  VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(),
+                                    key2.as<uint32_t>(), idx.as<uint32_t>(),
+                                    idx2.as<uint32_t>(), (size_t) n, 0u, bits,
+                                    stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, key.as<uint32_t>(),
+                                    key2.as<uint32_t>(), idx.as<uint32_t>(),
+                                    idx2.as<uint32_t>(), (size_t) n, 0u, bits,
+                                    stream));
+  k_partition_gather<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+      result->matches, idx2.as<uint32_t>(), n, (vsa_match *) device_matches);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipMemcpyAsync(counts, dcounts.p, nparts * 8, hipMemcpyDeviceToHost,
+                         stream));
+  VSA_HIP(hipStreamSynchronize(stream));
   return 0;
 }
 
