@@ -668,3 +668,30 @@ def test_mum_work_plan_on_ragged_batches(V, seed):
     assert np.array_equal(
         V.findquerymatches(gi, gq, L, mum=True).fetch(),
         H.oracle_querymatches(host, hq, L, mum=True, speedup=0))
+
+
+def test_unordered_candidates_and_partition_by_index_range(V):
+    """the multi-GPU building blocks: candidates as the kernel left them are
+    the ordered list as a set; vsa_result_partition groups them by the range
+    of the index their dbstart falls into, equal dbstarts together"""
+    idx, q = H.load_case("c1")
+    gi, gq = gpu_index(V, "c1"), gpu_queries(V, q)
+    ordered = V.findmumcandidates(gi, gq, 20, ordered=True).fetch()
+    assert np.array_equal(H.matches_as_ref(idx, ordered),
+                          H.expected("c1", "mumcand20"))
+    r = V.findmumcandidates(gi, gq, 20, ordered=False)
+    loose = r.fetch()
+    assert np.array_equal(np.sort(loose, order=list(loose.dtype.names)),
+                          np.sort(ordered, order=list(ordered.dtype.names)))
+    for nparts in (1, 2, 8, 5):
+        buf = V.device_malloc(max(r.count, 1) * 32)
+        counts = r.partition(nparts, idx.n, buf)
+        got = np.zeros(r.count, V.MATCH_DTYPE)
+        V.device_download(got, buf)
+        V.device_free(buf)
+        assert int(counts.sum()) == r.count
+        part = (got["dbstart"] * np.uint64(nparts)) // np.uint64(idx.n + 1)
+        assert np.array_equal(part, np.repeat(np.arange(nparts, dtype=np.uint64),
+                                              counts.astype(np.int64)))
+        assert np.array_equal(np.sort(got, order=list(got.dtype.names)),
+                              np.sort(ordered, order=list(ordered.dtype.names)))
