@@ -616,6 +616,12 @@ def device_upload(dptr, array, device=0):
     _check(lib.vsa_device_upload(dptr, _ptr(array), array.nbytes, device))
 
 
+def device_download(array, dptr, device=0):
+    """device memory -> a contiguous numpy array (its size decides)"""
+    assert array.flags["C_CONTIGUOUS"]
+    _check(lib.vsa_device_download(_ptr(array), dptr, array.nbytes, device))
+
+
 def device_free(p, device=0):
     _check(lib.vsa_device_free(p, device))
 
