@@ -60,6 +60,9 @@ def parse():
     # rehearsal of the N > 1 path on a box with ONE GPU: every rank uses
     # device 0 and the collectives run over gloo on host copies
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
+    # one rank, but through the N > 1 code path with the real backend (RCCL):
+    # process group, all-to-all / all-gather / all-reduce on device tensors
+    ap.add_argument("--force-distributed", action="store_true")
     return ap.parse_args()
 
 
@@ -93,13 +96,16 @@ def main():
     dev = 0 if a.rehearse_on_one_gpu else local_rank
 
     torch = dist = S = None
-    if world > 1:
+    distributed = world > 1 or a.force_distributed
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # torch first: its wheel bundles a HIP runtime, and the library must
         # bind to the one runtime of the process (vstree_amd/__init__.py)
         import torch
         import torch.distributed as dist
     import vstree_amd as V
-    if world > 1:
+    if distributed:
         from vstree_amd import sharding as S
         torch.cuda.set_device(dev)
         dist.init_process_group("gloo" if a.rehearse_on_one_gpu else "nccl",
@@ -133,7 +139,7 @@ def main():
 
     def sync():
         V.device_synchronize(dev)
-        if world > 1:
+        if distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -144,7 +150,7 @@ def main():
         """the hot path over the whole batch; returns (count, sumlength,
         searches, candidates) of the job"""
         nonlocal totals
-        if world == 1:
+        if not distributed:
             r = V.findquerymatches(index, queries, L, mum=True)
             s = r.stats()
             kernel_ms.append(s.search_kernel_ms)
@@ -192,7 +198,7 @@ def main():
         one_step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         e = torch.tensor([elapsed], dtype=torch.float64,
                          device="cpu" if a.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
@@ -310,7 +316,7 @@ def main():
                                                       rj["source"])}
             out["speedup_vs_cpu_1core"] = qps / (sample.nq / dt)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
