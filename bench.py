@@ -166,7 +166,7 @@ def main():
         kernel_ms.append(s.search_kernel_ms)
         mine = torch.empty(max(r.count, 1) * 4, dtype=torch.int64,
                            device="cuda")[:r.count * 4]
-        send = r.partition(world, n, C.c_void_p(mine.data_ptr()))
+        send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()))
         r.close()
         cdev = "cuda"
         if a.rehearse_on_one_gpu:
@@ -183,7 +183,7 @@ def main():
             return st.count, st.sumlength
 
         nmum, sumlen, ncand = S.partitioned_mum_filter_presorted(
-            dist, torch, mine, send, cdev, filter_fn)
+            dist, torch, mine, send, top, cdev, filter_fn)
         # final reduction of the remaining match counters
         searches, ksearches = S.all_reduce_counters(
             dist, torch, [s.searches, s.kernel_searches], cdev)

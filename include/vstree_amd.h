@@ -247,12 +247,15 @@ int vsa_findmumcandidates(const vsa_index *index, const vsa_queries *queries,
   falls into -- part p = floor(dbstart * nparts / (totallength + 1)), equal
   dbstarts in the same part -- written to device_matches (room for
   vsa_result_count records) part by part; counts[p] (host, nparts entries) =
-  records of part p.  The send buffer and the split sizes of the all-to-all
-  that brings every candidate to the rank filtering its range.
+  records of part p; maxright[p] (host, may be NULL) = the largest right end
+  dbstart + length - 1 among them, 0 if there is none.  The send buffer and
+  the split sizes of the all-to-all that brings every candidate to the rank
+  filtering its range, and what the ranks need to agree on the carry of
+  vsa_mumuniqueinquery_range without looking at the records again.
 */
 int vsa_result_partition(const vsa_result *result, uint32_t nparts,
                          uint64_t totallength, void *device_matches,
-                         uint64_t *counts);
+                         uint64_t *counts, uint64_t *maxright);
 
 /*
   findcompletematches for approximate matching on the index, vmatch

@@ -685,11 +685,17 @@ def test_unordered_candidates_and_partition_by_index_range(V):
                           np.sort(ordered, order=list(ordered.dtype.names)))
     for nparts in (1, 2, 8, 5):
         buf = V.device_malloc(max(r.count, 1) * 32)
-        counts = r.partition(nparts, idx.n, buf)
+        counts, top = r.partition(nparts, idx.n, buf)
         got = np.zeros(r.count, V.MATCH_DTYPE)
         V.device_download(got, buf)
         V.device_free(buf)
         assert int(counts.sum()) == r.count
+        right = ordered["dbstart"] + ordered["length"] - 1
+        opart = (ordered["dbstart"] * np.uint64(nparts)) // np.uint64(
+            idx.n + 1)
+        assert [int(x) for x in top] == [
+            int(right[opart == p].max()) if (opart == p).any() else 0
+            for p in range(nparts)]
         part = (got["dbstart"] * np.uint64(nparts)) // np.uint64(idx.n + 1)
         assert np.array_equal(part, np.repeat(np.arange(nparts, dtype=np.uint64),
                                               counts.astype(np.int64)))

@@ -64,8 +64,11 @@ def _worker(rank, world, port, outdir):
     dest = (shuffled["dbstart"] * np.uint64(world)) // np.uint64(idx.n + 1)
     grouped = shuffled[np.argsort(dest, kind="stable")]
     send = np.bincount(dest.astype(np.int64), minlength=world)
+    right = (shuffled["dbstart"] + shuffled["length"] - 1).astype(np.int64)
+    top = [int(right[dest == r].max()) if (dest == r).any() else 0
+           for r in range(world)]
     qn, qs_, qc = S.partitioned_mum_filter_presorted(
-        dist, torch, S.matches_to_tensor(torch, grouped), send, "cpu",
+        dist, torch, S.matches_to_tensor(torch, grouped), send, top, "cpu",
         range_filter_fn)
     assert (qn, qs_, qc) == (nmum, sumlen, ncand)
     pparts, _ = S.all_gather_matches(

@@ -139,7 +139,7 @@ def _load():
                                                  PROCESSMATCH, V]),
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
         "vsa_findmumcandidates": (I, [V, V, U64, I, PP]),
-        "vsa_result_partition": (I, [V, U32, U64, V, V]),
+        "vsa_result_partition": (I, [V, U32, U64, V, V, V]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
         "vsa_findmaximalrepeats": (I, [V, U64, PP]),
         "vsa_findmaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
@@ -341,12 +341,13 @@ class Result:
 
     def partition(self, nparts, totallength, device_ptr):
         """records grouped by the index range of their dbstart, written to
-        device_ptr; -> number of records per part"""
+        device_ptr; -> (number of records, largest right end) per part"""
         counts = np.zeros(nparts, np.uint64)
+        maxright = np.zeros(nparts, np.uint64)
         _check(lib.vsa_result_partition(self._h, int(nparts),
                                         int(totallength), device_ptr,
-                                        _ptr(counts)))
-        return counts
+                                        _ptr(counts), _ptr(maxright)))
+        return counts, maxright
 
     def fetch(self):
         n = self.count

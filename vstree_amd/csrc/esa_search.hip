@@ -1327,13 +1327,16 @@ __global__ void __launch_bounds__(VSA_BLOCK)
 k_partition_keys(const vsa_match *__restrict__ m, uint64_t n,
                  uint32_t nparts, uint64_t totallength,
                  uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
-                 unsigned long long *__restrict__ counts)
+                 unsigned long long *__restrict__ counts,
+                 unsigned long long *__restrict__ maxright)
 {
   __shared__ unsigned int hist[256];
+  __shared__ unsigned long long top[256];
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
   if (threadIdx.x < 256)
   {
     hist[threadIdx.x] = 0;
+    top[threadIdx.x] = 0;
   }
   __syncthreads();
   if (t < n)
@@ -1343,11 +1346,15 @@ k_partition_keys(const vsa_match *__restrict__ m, uint64_t n,
     key[t] = p;
     idx[t] = (uint32_t) t;
     atomicAdd(&hist[p], 1u);
+    // right end of the match in the index (cleanMUMcand.c: dbright)
+    atomicMax(&top[p],
+              (unsigned long long) (m[t].dbstart + m[t].length - 1));
   }
   __syncthreads();
   if (threadIdx.x < nparts && hist[threadIdx.x] != 0)
   {
     atomicAdd(counts + threadIdx.x, (unsigned long long) hist[threadIdx.x]);
+    atomicMax(maxright + threadIdx.x, top[threadIdx.x]);
   }
 }
 
@@ -1369,7 +1376,8 @@ k_partition_gather(const vsa_match *__restrict__ m,
 
 extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
                                     uint64_t totallength,
-                                    void *device_matches, uint64_t *counts)
+                                    void *device_matches, uint64_t *counts,
+                                    uint64_t *maxright)
 {
   if (result == nullptr || counts == nullptr || nparts == 0 ||
       nparts > 256 || (result->count > 0 && device_matches == nullptr))
@@ -1380,6 +1388,10 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   for (uint32_t p = 0; p < nparts; p++)
   {
     counts[p] = 0;
+    if (maxright != nullptr)
+    {
+      maxright[p] = 0;
+    }
   }
   const uint64_t n = result->count;
   if (n == 0)
@@ -1399,14 +1411,15 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   DevBuf key, key2, idx, idx2, dcounts, temp;
   size_t tb = 0;
   if (key.alloc(n * 4) || key2.alloc(n * 4) || idx.alloc(n * 4) ||
-      idx2.alloc(n * 4) || dcounts.alloc(256 * 8))
+      idx2.alloc(n * 4) || dcounts.alloc(2 * 256 * 8))
   {
     return -100;
   }
-  VSA_HIP(hipMemsetAsync(dcounts.p, 0, 256 * 8, stream));
+  VSA_HIP(hipMemsetAsync(dcounts.p, 0, 2 * 256 * 8, stream));
   k_partition_keys<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
       result->matches, n, nparts, totallength, key.as<uint32_t>(),
-      idx.as<uint32_t>(), dcounts.as<unsigned long long>());
+      idx.as<uint32_t>(), dcounts.as<unsigned long long>(),
+      dcounts.as<unsigned long long>() + 256);
   VSA_HIP(hipGetLastError());
   const unsigned int bits = bitsfor(nparts - 1);
   VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(),
@@ -1426,6 +1439,11 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipMemcpyAsync(counts, dcounts.p, nparts * 8, hipMemcpyDeviceToHost,
                          stream));
+  if (maxright != nullptr)
+  {
+    VSA_HIP(hipMemcpyAsync(maxright, dcounts.as<uint64_t>() + 256, nparts * 8,
+                           hipMemcpyDeviceToHost, stream));
+  }
   VSA_HIP(hipStreamSynchronize(stream));
   return 0;
 }

@@ -93,44 +93,40 @@ def _exchange_rows(dist, torch, rows, dest, device):
         return torch.cat(keep) if keep else rows[:0]
 
 
-def _exchange_presorted(dist, torch, rows, send, device):
-    """rows [N,4] int64 already grouped by receiving rank, send[r] = rows for
-    rank r -> the rows every rank addressed to this rank, in rank order"""
+def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
+                                     device, filter_fn):
+    """partitioned_mum_filter for candidates that vsa_result_partition has
+    grouped by destination already (send[r] rows for rank r, maxright[r] =
+    their largest right end): no sorting on this side and three collectives --
+    one all-gather of the 2*world numbers of every rank (split sizes of the
+    exchange and the carries), the all-to-all of the rows, the all-reduce of
+    the counters."""
     world, me = dist.get_world_size(), dist.get_rank()
-    send = torch.as_tensor(np.asarray(send, np.int64), device=device)
-    recv = torch.zeros_like(send)
+    rows = rows.reshape(-1, MATCH_WORDS)
+    meta = torch.as_tensor(np.concatenate([np.asarray(send, np.int64),
+                                           np.asarray(maxright, np.int64)]),
+                           device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    table = torch.stack(metas).cpu().numpy()        # [sender, 2*world]
+    sends, tops = table[:, :world], table[:, world:]
+    recv = [int(x) for x in sends[:, me]]
+    # largest right end among ALL candidates of the ranges below mine
+    carry = int(tops[:, :me].max()) if me > 0 else 0
+    mine = torch.empty((sum(recv), MATCH_WORDS), dtype=torch.int64,
+                       device=device)
     try:
-        dist.all_to_all_single(recv, send)
-        out = torch.empty((int(recv.sum().item()), MATCH_WORDS),
-                          dtype=torch.int64, device=device)
-        dist.all_to_all_single(out, rows, recv.tolist(), send.tolist())
-        return out
+        dist.all_to_all_single(mine, rows, recv,
+                               [int(x) for x in sends[me]])
     except (RuntimeError, NotImplementedError):
         # backend without all-to-all (gloo in the CPU tests): gather all,
         # cut out what is addressed to this rank
         parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device)
-        sends = [torch.zeros_like(send) for _ in range(world)]
-        dist.all_gather(sends, send)
         keep = []
-        for p, sd in zip(parts, sends):
-            off = int(sd[:me].sum().item())
-            keep.append(p.reshape(-1, MATCH_WORDS)[off:off + int(sd[me])])
-        return torch.cat(keep) if keep else rows[:0]
-
-
-def partitioned_mum_filter_presorted(dist, torch, rows, send, device,
-                                     filter_fn):
-    """partitioned_mum_filter for candidates that vsa_result_partition has
-    grouped by destination already: no sorting on this side"""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    rows = rows.reshape(-1, MATCH_WORDS)
-    mine = _exchange_presorted(dist, torch, rows, send, device)
-    localmax = torch.zeros(1, dtype=torch.int64, device=device)
-    if mine.shape[0] > 0:
-        localmax[0] = (mine[:, 1] + mine[:, 0] - 1).max()
-    allmax = [torch.zeros_like(localmax) for _ in range(world)]
-    dist.all_gather(allmax, localmax)
-    carry = max([0] + [int(m.item()) for m in allmax[:rank]])
+        for r, p in enumerate(parts):
+            off = int(sends[r, :me].sum())
+            keep.append(p.reshape(-1, MATCH_WORDS)[off:off + recv[r]])
+        mine = torch.cat(keep) if keep else rows[:0]
     nmum, sumlen = filter_fn(mine.reshape(-1), carry)
     nmum, sumlen, ncand = all_reduce_counters(
         dist, torch, [nmum, sumlen, rows.shape[0]], device)
