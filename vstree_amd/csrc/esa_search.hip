@@ -1322,15 +1322,13 @@ extern "C" int vsa_findmumcandidates(const vsa_index *index,
 }
 
 // records of a result by the range of the index their dbstart falls into:
-// part p = floor(dbstart * nparts / (totallength + 1)).  Two passes without a
-// sort (the order inside a part is free): counts and largest right ends per
-// part, then every wavefront reserves room part by part (one atomic per
-// wavefront and part present in it) and writes its records.
+// part p = floor(dbstart * nparts / (totallength + 1))
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_partition_count(const vsa_match *__restrict__ m, uint64_t n,
-                  uint32_t nparts, uint64_t totallength,
-                  unsigned long long *__restrict__ counts,
-                  unsigned long long *__restrict__ maxright)
+k_partition_keys(const vsa_match *__restrict__ m, uint64_t n,
+                 uint32_t nparts, uint64_t totallength,
+                 uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+                 unsigned long long *__restrict__ counts,
+                 unsigned long long *__restrict__ maxright)
 {
   __shared__ unsigned int hist[256];
   __shared__ unsigned long long top[256];
@@ -1345,6 +1343,8 @@ k_partition_count(const vsa_match *__restrict__ m, uint64_t n,
   {
     const uint32_t p =
         (uint32_t) ((m[t].dbstart * nparts) / (totallength + 1));
+    key[t] = p;
+    idx[t] = (uint32_t) t;
     atomicAdd(&hist[p], 1u);
     // right end of the match in the index (cleanMUMcand.c: dbright)
     atomicMax(&top[p],
@@ -1359,46 +1359,18 @@ k_partition_count(const vsa_match *__restrict__ m, uint64_t n,
 }
 
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_partition_scatter(const vsa_match *__restrict__ m, uint64_t n,
-                    uint32_t nparts, uint64_t totallength,
-                    unsigned long long *__restrict__ cursors,
-                    vsa_match *__restrict__ out)
+k_partition_gather(const vsa_match *__restrict__ m,
+                   const uint32_t *__restrict__ idx, uint64_t n,
+                   vsa_match *__restrict__ out)
 {
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  const bool active = t < n;
-  const uint32_t lane = threadIdx.x & 63;
-  uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-  uint32_t p = 0xFFFFFFFFu;
-  if (active)
+  if (t < n)
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(m + t);
-    lo = src[0];
-    hi = src[1];
-    const uint64_t dbstart = ((uint64_t) lo.w << 32) | lo.z;
-    p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
-  }
-  uint64_t remaining = __ballot(active);
-  while (remaining != 0)
-  {
-    const int leader = __builtin_ctzll(remaining);
-    const uint32_t pd = __shfl(p, leader, 64);
-    const uint64_t same = __ballot(active && p == pd);
-    unsigned long long base = 0;
-    if ((int) lane == leader)
-    {
-      base = atomicAdd(cursors + pd,
-                       (unsigned long long) __builtin_popcountll(same));
-    }
-    base = __shfl(base, leader, 64);
-    if (active && p == pd)
-    {
-      const uint64_t rank =
-          (uint64_t) __builtin_popcountll(same & ((1ull << lane) - 1));
-      uint4 *dst = reinterpret_cast<uint4 *>(out + base + rank);
-      dst[0] = lo;
-      dst[1] = hi;
-    }
-    remaining &= ~same;
+    const uint4 *src = reinterpret_cast<const uint4 *>(m + idx[t]);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + t);
+    const uint4 lo = src[0], hi = src[1];
+    dst[0] = lo;
+    dst[1] = hi;
   }
 }
 
@@ -1426,44 +1398,52 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   {
     return 0;
   }
+  if (n >= 0xFFFFFFFFull)
+  {
+    VSA_ERROR("vsa_result_partition: more than 2^32 records");
+    return -3;
+  }
   if (vsa_set_device(result->device) != 0)
   {
     return -100;
   }
   hipStream_t stream = nullptr;
-  DevBuf dcounts;
-  uint64_t host[3 * 256];
-  if (dcounts.alloc(3 * 256 * 8))
+  DevBuf key, key2, idx, idx2, dcounts, temp;
+  size_t tb = 0;
+  if (key.alloc(n * 4) || key2.alloc(n * 4) || idx.alloc(n * 4) ||
+      idx2.alloc(n * 4) || dcounts.alloc(2 * 256 * 8))
   {
     return -100;
   }
-  VSA_HIP(hipMemsetAsync(dcounts.p, 0, 3 * 256 * 8, stream));
-  k_partition_count<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
-      result->matches, n, nparts, totallength,
-      dcounts.as<unsigned long long>(),
+  VSA_HIP(hipMemsetAsync(dcounts.p, 0, 2 * 256 * 8, stream));
+  k_partition_keys<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+      result->matches, n, nparts, totallength, key.as<uint32_t>(),
+      idx.as<uint32_t>(), dcounts.as<unsigned long long>(),
       dcounts.as<unsigned long long>() + 256);
   VSA_HIP(hipGetLastError());
-  VSA_HIP(hipMemcpyAsync(host, dcounts.p, 2 * 256 * 8, hipMemcpyDeviceToHost,
-                         stream));
-  VSA_HIP(hipStreamSynchronize(stream));
-  uint64_t acc = 0;
-  for (uint32_t p = 0; p < nparts; p++)
+  const unsigned int bits = bitsfor(nparts - 1);
+  VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(),
+                                    key2.as<uint32_t>(), idx.as<uint32_t>(),
+                                    idx2.as<uint32_t>(), (size_t) n, 0u, bits,
+                                    stream));
+  if (temp.alloc(tb))
   {
-    counts[p] = host[p];
-    if (maxright != nullptr)
-    {
-      maxright[p] = host[256 + p];
-    }
-    host[2 * 256 + p] = acc; // where part p starts
-    acc += host[p];
+    return -100;
   }
-  VSA_HIP(hipMemcpyAsync(dcounts.as<uint64_t>() + 2 * 256, host + 2 * 256,
-                         nparts * 8, hipMemcpyHostToDevice, stream));
-  k_partition_scatter<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
-      result->matches, n, nparts, totallength,
-      dcounts.as<unsigned long long>() + 2 * 256,
-      (vsa_match *) device_matches);
+  VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, key.as<uint32_t>(),
+                                    key2.as<uint32_t>(), idx.as<uint32_t>(),
+                                    idx2.as<uint32_t>(), (size_t) n, 0u, bits,
+                                    stream));
+  k_partition_gather<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+      result->matches, idx2.as<uint32_t>(), n, (vsa_match *) device_matches);
   VSA_HIP(hipGetLastError());
+  VSA_HIP(hipMemcpyAsync(counts, dcounts.p, nparts * 8, hipMemcpyDeviceToHost,
+                         stream));
+  if (maxright != nullptr)
+  {
+    VSA_HIP(hipMemcpyAsync(maxright, dcounts.as<uint64_t>() + 256, nparts * 8,
+                           hipMemcpyDeviceToHost, stream));
+  }
   VSA_HIP(hipStreamSynchronize(stream));
   return 0;
 }
