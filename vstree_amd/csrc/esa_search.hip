@@ -378,8 +378,11 @@ k_mum_gather(const vsa_match *__restrict__ cand,
 // the largest right end in this list.
 int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
                      DevBuf &mums, uint64_t *nmums, uint64_t carry = 0,
-                     uint64_t *maxright = nullptr)
+                     uint64_t *maxright = nullptr, uint64_t dbbound = 0,
+                     uint64_t lenbound = 0)
 {
+  // dbbound / lenbound: upper bounds of dbstart and length if the caller
+  // knows them (index length, longest query), else 0: they are looked up
   *nmums = 0;
   if (maxright != nullptr)
   {
@@ -398,6 +401,9 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   }
   // how many bits do dbstart and length need?
   MaxPair mx;
+  mx.db = dbbound;
+  mx.len = lenbound;
+  if (dbbound == 0 || lenbound == 0)
   {
     size_t tb = 0;
     auto in = rocprim::make_transform_iterator(cand.as<vsa_match>(),
@@ -915,7 +921,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     DevBuf mums;
     uint64_t nm = 0;
-    if (mumuniqueinquery(out, needed, stream, mums, &nm))
+    if (mumuniqueinquery(out, needed, stream, mums, &nm, 0, nullptr,
+                         index->n, queries->maxlength))
     {
       return -100;
     }
