@@ -1329,53 +1329,106 @@ extern "C" int vsa_findmumcandidates(const vsa_index *index,
 }
 
 // records of a result by the range of the index their dbstart falls into:
-// part p = floor(dbstart * nparts / (totallength + 1))
+// part p = floor(dbstart * nparts / (totallength + 1)).  A counting sort in
+// two passes over the records (the order inside a part is free): per
+// workgroup and part a count (and the largest right end), one exclusive scan
+// over the counts laid out part-major = the place of every (part, workgroup)
+// in the output, then every workgroup puts its records there.  No global
+// atomics: a cursor word per part would take one returning atomic per
+// wavefront, which is slower than the whole rest (measured).
+#define VSA_PART_MAX 256
+
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_partition_keys(const vsa_match *__restrict__ m, uint64_t n,
-                 uint32_t nparts, uint64_t totallength,
-                 uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
-                 unsigned long long *__restrict__ counts,
-                 unsigned long long *__restrict__ maxright)
+k_partition_count(const vsa_match *__restrict__ m, uint64_t n,
+                  uint32_t nparts, uint64_t totallength, uint64_t nblocks,
+                  uint32_t *__restrict__ blockhist,
+                  unsigned long long *__restrict__ blocktop)
 {
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned long long top[256];
+  __shared__ unsigned int hist[VSA_PART_MAX];
+  __shared__ unsigned long long top[VSA_PART_MAX];
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (threadIdx.x < 256)
+  for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
   {
-    hist[threadIdx.x] = 0;
-    top[threadIdx.x] = 0;
+    hist[p] = 0;
+    top[p] = 0;
   }
   __syncthreads();
   if (t < n)
   {
     const uint32_t p =
         (uint32_t) ((m[t].dbstart * nparts) / (totallength + 1));
-    key[t] = p;
-    idx[t] = (uint32_t) t;
     atomicAdd(&hist[p], 1u);
     // right end of the match in the index (cleanMUMcand.c: dbright)
     atomicMax(&top[p],
               (unsigned long long) (m[t].dbstart + m[t].length - 1));
   }
   __syncthreads();
-  if (threadIdx.x < nparts && hist[threadIdx.x] != 0)
+  for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
   {
-    atomicAdd(counts + threadIdx.x, (unsigned long long) hist[threadIdx.x]);
-    atomicMax(maxright + threadIdx.x, top[threadIdx.x]);
+    blockhist[(uint64_t) p * nblocks + blockIdx.x] = hist[p];
+    blocktop[(uint64_t) p * nblocks + blockIdx.x] = top[p];
+  }
+}
+
+// per part: where it starts in the output and its largest right end
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_partition_summary(const uint64_t *__restrict__ offsets,
+                    const unsigned long long *__restrict__ blocktop,
+                    uint32_t nparts, uint64_t nblocks,
+                    uint64_t *__restrict__ partstart,
+                    unsigned long long *__restrict__ parttop)
+{
+  __shared__ unsigned long long red[VSA_BLOCK];
+  const uint32_t p = blockIdx.x;
+  unsigned long long best = 0;
+  for (uint64_t b = threadIdx.x; b < nblocks; b += VSA_BLOCK)
+  {
+    const unsigned long long v = blocktop[(uint64_t) p * nblocks + b];
+    best = v > best ? v : best;
+  }
+  red[threadIdx.x] = best;
+  __syncthreads();
+  for (int d = VSA_BLOCK / 2; d > 0; d >>= 1)
+  {
+    if ((int) threadIdx.x < d && red[threadIdx.x + d] > red[threadIdx.x])
+    {
+      red[threadIdx.x] = red[threadIdx.x + d];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    parttop[p] = red[0];
+    partstart[p] = offsets[(uint64_t) p * nblocks];
+    if (p + 1 == nparts)
+    {
+      partstart[nparts] = offsets[(uint64_t) nparts * nblocks];
+    }
   }
 }
 
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_partition_gather(const vsa_match *__restrict__ m,
-                   const uint32_t *__restrict__ idx, uint64_t n,
-                   vsa_match *__restrict__ out)
+k_partition_place(const vsa_match *__restrict__ m, uint64_t n,
+                  uint32_t nparts, uint64_t totallength, uint64_t nblocks,
+                  const uint64_t *__restrict__ offsets,
+                  vsa_match *__restrict__ out)
 {
+  __shared__ unsigned int taken[VSA_PART_MAX];
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
+  {
+    taken[p] = 0;
+  }
+  __syncthreads();
   if (t < n)
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(m + idx[t]);
-    uint4 *dst = reinterpret_cast<uint4 *>(out + t);
+    const uint4 *src = reinterpret_cast<const uint4 *>(m + t);
     const uint4 lo = src[0], hi = src[1];
+    const uint64_t dbstart = ((uint64_t) lo.w << 32) | lo.z;
+    const uint32_t p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
+    const uint64_t slot = offsets[(uint64_t) p * nblocks + blockIdx.x] +
+                          atomicAdd(&taken[p], 1u);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + slot);
     dst[0] = lo;
     dst[1] = hi;
   }
@@ -1387,7 +1440,8 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
                                     uint64_t *maxright)
 {
   if (result == nullptr || counts == nullptr || nparts == 0 ||
-      nparts > 256 || (result->count > 0 && device_matches == nullptr))
+      nparts > VSA_PART_MAX ||
+      (result->count > 0 && device_matches == nullptr))
   {
     VSA_ERROR("vsa_result_partition: bad argument (1..256 parts)");
     return -1;
@@ -1405,53 +1459,58 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   {
     return 0;
   }
-  if (n >= 0xFFFFFFFFull)
-  {
-    VSA_ERROR("vsa_result_partition: more than 2^32 records");
-    return -3;
-  }
   if (vsa_set_device(result->device) != 0)
   {
     return -100;
   }
   hipStream_t stream = nullptr;
-  DevBuf key, key2, idx, idx2, dcounts, temp;
+  const uint64_t nblocks = gridfor(n), cells = (uint64_t) nparts * nblocks;
+  DevBuf hist, top, offsets, summary, temp;
+  uint64_t host[2 * VSA_PART_MAX + 1];
   size_t tb = 0;
-  if (key.alloc(n * 4) || key2.alloc(n * 4) || idx.alloc(n * 4) ||
-      idx2.alloc(n * 4) || dcounts.alloc(2 * 256 * 8))
+  if (hist.alloc((cells + 1) * 4) || top.alloc(cells * 8) ||
+      offsets.alloc((cells + 1) * 8) ||
+      summary.alloc((2 * VSA_PART_MAX + 1) * 8))
   {
     return -100;
   }
-  VSA_HIP(hipMemsetAsync(dcounts.p, 0, 2 * 256 * 8, stream));
-  k_partition_keys<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
-      result->matches, n, nparts, totallength, key.as<uint32_t>(),
-      idx.as<uint32_t>(), dcounts.as<unsigned long long>(),
-      dcounts.as<unsigned long long>() + 256);
+  VSA_HIP(hipMemsetAsync(hist.as<uint32_t>() + cells, 0, 4, stream));
+  k_partition_count<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
+      result->matches, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
+      top.as<unsigned long long>());
   VSA_HIP(hipGetLastError());
-  const unsigned int bits = bitsfor(nparts - 1);
-  VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, key.as<uint32_t>(),
-                                    key2.as<uint32_t>(), idx.as<uint32_t>(),
-                                    idx2.as<uint32_t>(), (size_t) n, 0u, bits,
-                                    stream));
+  auto widen = rocprim::make_transform_iterator(hist.as<uint32_t>(),
+                                                U32ToU64());
+  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, widen, offsets.as<uint64_t>(),
+                                  (uint64_t) 0, (size_t) (cells + 1),
+                                  rocprim::plus<uint64_t>(), stream));
   if (temp.alloc(tb))
   {
     return -100;
   }
-  VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, key.as<uint32_t>(),
-                                    key2.as<uint32_t>(), idx.as<uint32_t>(),
-                                    idx2.as<uint32_t>(), (size_t) n, 0u, bits,
-                                    stream));
-  k_partition_gather<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
-      result->matches, idx2.as<uint32_t>(), n, (vsa_match *) device_matches);
+  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, widen, offsets.as<uint64_t>(),
+                                  (uint64_t) 0, (size_t) (cells + 1),
+                                  rocprim::plus<uint64_t>(), stream));
+  k_partition_summary<<<nparts, VSA_BLOCK, 0, stream>>>(
+      offsets.as<uint64_t>(), top.as<unsigned long long>(), nparts, nblocks,
+      summary.as<uint64_t>(),
+      summary.as<unsigned long long>() + VSA_PART_MAX + 1);
   VSA_HIP(hipGetLastError());
-  VSA_HIP(hipMemcpyAsync(counts, dcounts.p, nparts * 8, hipMemcpyDeviceToHost,
-                         stream));
-  if (maxright != nullptr)
-  {
-    VSA_HIP(hipMemcpyAsync(maxright, dcounts.as<uint64_t>() + 256, nparts * 8,
-                           hipMemcpyDeviceToHost, stream));
-  }
+  k_partition_place<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
+      result->matches, n, nparts, totallength, nblocks,
+      offsets.as<uint64_t>(), (vsa_match *) device_matches);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipMemcpyAsync(host, summary.p, (2 * VSA_PART_MAX + 1) * 8,
+                         hipMemcpyDeviceToHost, stream));
   VSA_HIP(hipStreamSynchronize(stream));
+  for (uint32_t p = 0; p < nparts; p++)
+  {
+    counts[p] = host[p + 1] - host[p];
+    if (maxright != nullptr)
+    {
+      maxright[p] = host[VSA_PART_MAX + 1 + p];
+    }
+  }
   return 0;
 }
 
