@@ -493,9 +493,11 @@ template <int AHEAD = 1>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
-                uint64_t &w, DeepHit &hit)
+                uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu)
 {
-  // AHEAD: see vsa_compare32
+  // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
+  // of at least this length (the MUM test); the default never fetches it --
+  // it is a random text access of its own for every non-empty bucket.
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
@@ -705,7 +707,7 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   }
   // the symbol in front of the located suffix (left maximality) travels
   // with the first text words: one round trip less.  Front pad = separator.
-  if (state == VSA_LOC_FOUND)
+  if (state == VSA_LOC_FOUND && (extend || maxlcp >= needleft))
   {
     hit.leftsym = ix.tis[(int64_t) (hit.ew & 0xFFFFFFFFull) - 1];
   }
