@@ -223,6 +223,7 @@ extern "C" void vsa_index_close(vsa_index *ix)
   (void) hipFree(ix->bwt);
   (void) hipFree(ix->esa8);
   (void) hipFree(ix->bck2);
+  (void) hipFree(ix->slot16);
   if (ix->stream != nullptr)
   {
     (void) hipStreamDestroy(ix->stream);

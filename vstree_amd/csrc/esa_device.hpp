@@ -502,6 +502,7 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
   uint32_t dl = 0, cnt = 0, qkey = 0, limit = 0;
+  uint64_t first = 0; // esa8[dl] from the fused table
 
   if (active)
   {
@@ -545,9 +546,19 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
       {
         limit = VSA_KEYSYMS;
       }
-      // (left, mid) of the deep bucket: one 8-byte load
-      const uint64_t b = vsa_ld_entry(
-          reinterpret_cast<const uint64_t *>(ix.bck2) + code, nt);
+      // (left, mid) of the deep bucket -- with the first entry of the
+      // bucket if the fused table is there: one load
+      uint64_t b;
+      if (ix.slot16 != nullptr)
+      {
+        const vsa_u128 sl = vsa_load16(ix.slot16 + 2 * code);
+        b = sl.lo;
+        first = sl.hi;
+      } else
+      {
+        b = vsa_ld_entry(reinterpret_cast<const uint64_t *>(ix.bck2) + code,
+                         nt);
+      }
       dl = (uint32_t) b;
       const uint32_t dm = (uint32_t) (b >> 32);
       cnt = (dm > dl) ? dm - dl : 0;
@@ -564,7 +575,14 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   const bool small = searching && cnt <= 4;
   const uint32_t ksh = 2 * (VSA_KEYSYMS - limit);
   uint64_t e[5] = {0, 0, 0, 0, 0};
-  if (small)
+  if (small && cnt == 1 && ix.slot16 != nullptr)
+  {
+    // a bucket of one suffix: its entry came with the bounds.  The entry
+    // behind it belongs to another bucket and shares fewer than D symbols
+    // with it, so its lcp byte (0 here) is below every match length either
+    // way: nothing else is needed.
+    e[0] = first;
+  } else if (small)
   {
     // esa8 has eight entries of slack behind index n
     const uint64_t *p = ix.esa8 + (uint64_t) dl;

@@ -1150,6 +1150,21 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
             (key << VSA_KEYSHIFT) | flag;
 }
 
+// slot16[code] = (bck2 pair, first entry of the bucket)
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_make_slot16(const uint32_t *__restrict__ bck2,
+              const uint64_t *__restrict__ esa8, uint64_t ncodes,
+              uint64_t *__restrict__ slot16)
+{
+  for (uint64_t c = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+       c < ncodes; c += (uint64_t) gridDim.x * VSA_BLOCK)
+  {
+    const uint32_t left = bck2[2 * c], mid = bck2[2 * c + 1];
+    slot16[2 * c] = (uint64_t) left | ((uint64_t) mid << 32);
+    slot16[2 * c + 1] = (mid > left) ? esa8[left] : 0;
+  }
+}
+
 int vsa_index_make_esa8(vsa_index *ix)
 {
   const char *off = getenv("VSA_NO_ESA8");
@@ -1162,6 +1177,11 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     (void) hipFree(ix->bck2);
     ix->bck2 = nullptr;
+  }
+  if (ix->slot16 != nullptr)
+  {
+    (void) hipFree(ix->slot16);
+    ix->slot16 = nullptr;
   }
   if (ix->numofchars != 4 || ix->isize != 4 || ix->bck == nullptr ||
       (off != nullptr && strcmp(off, "1") == 0))
@@ -1208,6 +1228,22 @@ int vsa_index_make_esa8(vsa_index *ix)
       count, D, ix->esa8);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(ix->stream));
+  // the fused table takes the place of bck2 (16 instead of 8 bytes per deep
+  // prefix); VSA_SLOT16=0 keeps bck2
+  const char *noslot = getenv("VSA_SLOT16");
+  if (!(noslot != nullptr && strcmp(noslot, "0") == 0))
+  {
+    VSA_HIP(hipMalloc((void **) &ix->slot16, 2 * ncodes * 8 + 16));
+    k_make_slot16<<<(unsigned int) std::min<uint64_t>(
+                        (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20),
+                    VSA_BLOCK, 0, ix->stream>>>(ix->bck2, ix->esa8, ncodes,
+                                                ix->slot16);
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipStreamSynchronize(ix->stream));
+    (void) hipFree(ix->bck2);
+    ix->bck2 = nullptr;
+    ix->device_bytes += 2 * ncodes * 4;
+  }
   return 0;
 }
 

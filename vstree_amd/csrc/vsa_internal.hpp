@@ -61,6 +61,11 @@ struct DevIndex
   // bck2 [2*4^D] (left, mid) pairs like bck, for D >= pl symbols.
   const uint64_t *esa8;
   const uint32_t *bck2;
+  // slot16 [2*4^D] u64: per deep prefix (left | mid << 32, esa8[left]): the
+  // bucket bounds AND its first entry in one 16-byte load; replaces bck2
+  // when present (a bucket of one suffix -- the usual non-empty bucket --
+  // then needs no second access)
+  const uint64_t *slot16;
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars, D;
   uint32_t tune; // experiment switches (VSA_TUNE), see esa_search.hip
@@ -83,6 +88,7 @@ struct vsa_index
   uint8_t *lcp, *bwt;
   uint64_t *esa8; // deep-locate tables, see DevIndex (may be nullptr)
   uint32_t *bck2;
+  uint64_t *slot16;
   uint32_t D, tune;
   uint64_t querysepposition;
   int hasindexedqueries;
@@ -104,6 +110,7 @@ struct vsa_index
     v.bwt = bwt;
     v.esa8 = esa8;
     v.bck2 = bck2;
+    v.slot16 = slot16;
     v.D = D;
     v.tune = tune;
     v.n = n;
