@@ -357,20 +357,6 @@ k_mum_compositekeys(const vsa_match *__restrict__ cand, uint64_t n,
   }
 }
 
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_mum_gather(const vsa_match *__restrict__ cand,
-             const uint32_t *__restrict__ idx, uint64_t n,
-             vsa_match *__restrict__ sorted, uint64_t *__restrict__ rightend)
-{
-  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-  if (i < n)
-  {
-    const vsa_match m = cand[idx[i]];
-    sorted[i] = m;
-    rightend[i] = m.dbstart + m.length - 1;
-  }
-}
-
 // carry = the reference's running `dbright` when it reaches the first of
 // these candidates: 0 for a whole job, the largest right end of all
 // candidates with a smaller dbstart when the list is one dbstart range of a
@@ -379,8 +365,10 @@ k_mum_gather(const vsa_match *__restrict__ cand,
 int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
                      DevBuf &mums, uint64_t *nmums, uint64_t carry = 0,
                      uint64_t *maxright = nullptr, uint64_t dbbound = 0,
-                     uint64_t lenbound = 0)
+                     uint64_t lenbound = 0, uint64_t *sumlength = nullptr)
 {
+  // *sumlength (if asked for) = sum of the lengths of the MUMs, or ~0 if this
+  // call did not compute it
   // dbbound / lenbound: upper bounds of dbstart and length if the caller
   // knows them (index length, longest query), else 0: they are looked up
   *nmums = 0;
@@ -388,14 +376,18 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   {
     *maxright = 0;
   }
+  if (sumlength != nullptr)
+  {
+    *sumlength = (ncand == 0) ? 0 : ~0ull;
+  }
   if (ncand == 0)
   {
     return 0;
   }
-  DevBuf ends, dbright, keep, temp, dcount, sorted;
+  DevBuf ends, dbright, keep, temp, dcount, sorted, k1, k2, i1, i2;
+  bool onkeys = false; // the filter runs on the sorted composite keys
   if (ends.alloc(ncand * 8) || dbright.alloc(ncand * 8) ||
-      keep.alloc(ncand) || dcount.alloc(sizeof(MaxPair)) ||
-      sorted.alloc(ncand * sizeof(vsa_match)))
+      keep.alloc(ncand) || dcount.alloc(sizeof(MaxPair) + 16))
   {
     return -100;
   }
@@ -425,9 +417,9 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   const unsigned int lenbits = bitsfor(mx.len), dbbits = bitsfor(mx.db);
   if (lenbits + dbbits <= 64 && ncand < 0xFFFFFFFFull)
   {
-    // one radix sort of (composite key, index) over just the bits in use,
-    // then one gather
-    DevBuf k1, k2, i1, i2;
+    // one radix sort of (composite key, index) over just the bits in use;
+    // the keys carry all the filter looks at
+    onkeys = true;
     if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || i1.alloc(ncand * 4) ||
         i2.alloc(ncand * 4))
     {
@@ -448,16 +440,16 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
     VSA_HIP(rocprim::radix_sort_pairs(
         temp.p, tb, k1.as<uint64_t>(), k2.as<uint64_t>(), i1.as<uint32_t>(),
         i2.as<uint32_t>(), (size_t) ncand, 0u, lenbits + dbbits, stream));
-    k_mum_gather<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-        cand.as<vsa_match>(), i2.as<uint32_t>(), ncand,
-        sorted.as<vsa_match>(), ends.as<uint64_t>());
+    k_mum_keyends<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        k2.as<uint64_t>(), ncand, lenbits, ends.as<uint64_t>());
     VSA_HIP(hipGetLastError());
   } else
   {
     // wide values: least significant key first (length descending), then a
     // stable sort by dbstart
-    DevBuf k1, k2, kout;
-    if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || kout.alloc(ncand * 8))
+    DevBuf kout;
+    if (k1.alloc(ncand * 8) || k2.alloc(ncand * 8) || kout.alloc(ncand * 8) ||
+        sorted.alloc(ncand * sizeof(vsa_match)))
     {
       return -100;
     }
@@ -509,14 +501,74 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
     VSA_HIP(hipStreamSynchronize(stream));
     *maxright = std::max(lastend, lastmax);
   }
-  k_mum_flags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-      sorted.as<vsa_match>(), ends.as<uint64_t>(), dbright.as<uint64_t>(),
-      ncand, keep.as<uint8_t>());
-  VSA_HIP(hipGetLastError());
   if (mums.alloc(ncand * sizeof(vsa_match)))
   {
     return -100;
   }
+  if (onkeys)
+  {
+    DevBuf slots;
+    uint64_t hsum = 0;
+    if (slots.alloc(ncand * 4))
+    {
+      return -100;
+    }
+    k_mum_keyflags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+        k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
+        lenbits, keep.as<uint8_t>());
+    VSA_HIP(hipGetLastError());
+    auto keepit =
+        rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
+    tb = 0;
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, keepit, slots.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) ncand,
+                                    rocprim::plus<uint32_t>(), stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) ncand,
+                                    rocprim::plus<uint32_t>(), stream));
+    DevBuf blocksum;
+    const size_t nblocks = gridfor(ncand);
+    if (blocksum.alloc(nblocks * 8))
+    {
+      return -100;
+    }
+    k_mum_writekept<<<nblocks, VSA_BLOCK, 0, stream>>>(
+        cand.as<vsa_match>(), i2.as<uint32_t>(), keep.as<uint8_t>(),
+        slots.as<uint32_t>(), ncand, mums.as<vsa_match>(),
+        dcount.as<uint64_t>(), blocksum.as<unsigned long long>());
+    VSA_HIP(hipGetLastError());
+    tb = 0;
+    VSA_HIP(rocprim::reduce(nullptr, tb, blocksum.as<unsigned long long>(),
+                            dcount.as<unsigned long long>() + 1, 0ull,
+                            nblocks, rocprim::plus<unsigned long long>(),
+                            stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::reduce(temp.p, tb, blocksum.as<unsigned long long>(),
+                            dcount.as<unsigned long long>() + 1, 0ull,
+                            nblocks, rocprim::plus<unsigned long long>(),
+                            stream));
+    VSA_HIP(hipMemcpyAsync(&hsum, dcount.as<uint64_t>() + 1, 8,
+                           hipMemcpyDeviceToHost, stream));
+    VSA_HIP(hipMemcpyAsync(nmums, dcount.p, 8, hipMemcpyDeviceToHost,
+                           stream));
+    VSA_HIP(hipStreamSynchronize(stream));
+    if (sumlength != nullptr)
+    {
+      *sumlength = hsum;
+    }
+    return 0;
+  }
+  k_mum_flags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
+      sorted.as<vsa_match>(), ends.as<uint64_t>(), dbright.as<uint64_t>(),
+      ncand, keep.as<uint8_t>());
+  VSA_HIP(hipGetLastError());
   if (compact_matches(sorted.as<vsa_match>(), keep.as<uint8_t>(), ncand,
                       mums.as<vsa_match>(), dcount.as<uint64_t>(), stream))
   {
@@ -584,7 +636,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // MUM modes over batches of equal-length queries: anchor pass + work list
   DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist, wfirste,
       wfmlen, wfmdb, wfslot;
-  uint64_t plansearches = 0, nfirst = 0;
+  uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
   bool firstpass = false;
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
@@ -922,7 +974,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     DevBuf mums;
     uint64_t nm = 0;
     if (mumuniqueinquery(out, needed, stream, mums, &nm, 0, nullptr,
-                         index->n, queries->maxlength))
+                         index->n, queries->maxlength, &mumsum))
     {
       return -100;
     }
@@ -959,6 +1011,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   res->stats.anchor_ms = anchorms;
   res->stats.kernel_searches = nwork;
   res->stats.total_device_ms = tall.ms();
+  if (mumsum != ~0ull)
+  {
+    res->stats.sumlength = mumsum; // the filter summed the lengths already
+    return 0;
+  }
   return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
 }
 
