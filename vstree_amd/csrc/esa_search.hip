@@ -118,6 +118,98 @@ struct Timer
   }
 };
 
+// Small results the host needs before it can go on (counts, maxima) come
+// back through a page of pinned memory: a device-to-host copy into pageable
+// memory is staged by the runtime and costs 30-150 us each, several times
+// per batch.  The page lives as long as the thread (never freed: the runtime
+// may be gone when thread-local destructors run).
+struct Fetch
+{
+  const void *src;
+  size_t bytes; // <= 8
+};
+
+inline int fetchwords(hipStream_t stream, const Fetch *items, int count,
+                      uint64_t *out)
+{
+  static thread_local uint64_t *page = nullptr;
+  if (page == nullptr)
+  {
+    void *v = nullptr;
+    VSA_HIP(hipHostMalloc(&v, 4096, hipHostMallocDefault));
+    page = (uint64_t *) v;
+  }
+  if (count > 512)
+  {
+    return -100;
+  }
+  for (int i = 0; i < count; i++)
+  {
+    page[i] = 0;
+    VSA_HIP(hipMemcpyAsync(page + i, items[i].src, items[i].bytes,
+                           hipMemcpyDeviceToHost, stream));
+  }
+  VSA_HIP(hipStreamSynchronize(stream));
+  for (int i = 0; i < count; i++)
+  {
+    out[i] = page[i];
+  }
+  return 0;
+}
+
+// offsets[sh] = sum of the fill counts of the cursor regions before sh;
+// summary = {total, largest count, *extra_a, *extra_b}: one workgroup
+__global__ void __launch_bounds__(1024)
+k_shard_summary(const unsigned long long *__restrict__ cursors,
+                uint32_t nshards, uint64_t *__restrict__ offsets,
+                const uint32_t *__restrict__ extra_a,
+                const uint32_t *__restrict__ extra_b,
+                uint64_t *__restrict__ summary)
+{
+  __shared__ uint64_t sums[1024], maxs[1024];
+  const uint32_t per = (nshards + 1023) / 1024, t = threadIdx.x;
+  uint64_t mine = 0, mx = 0;
+  for (uint32_t k = 0; k < per; k++)
+  {
+    const uint32_t sh = t * per + k;
+    if (sh < nshards)
+    {
+      const uint64_t c = cursors[(uint64_t) sh * VSA_CURSOR_STRIDE];
+      mine += c;
+      mx = c > mx ? c : mx;
+    }
+  }
+  sums[t] = mine;
+  maxs[t] = mx;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1)
+  {
+    const uint64_t a = t >= d ? sums[t - d] : 0,
+                   b = t >= d ? maxs[t - d] : 0;
+    __syncthreads();
+    sums[t] += a;
+    maxs[t] = b > maxs[t] ? b : maxs[t];
+    __syncthreads();
+  }
+  uint64_t run = sums[t] - mine;
+  for (uint32_t k = 0; k < per; k++)
+  {
+    const uint32_t sh = t * per + k;
+    if (sh < nshards)
+    {
+      offsets[sh] = run;
+      run += cursors[(uint64_t) sh * VSA_CURSOR_STRIDE];
+    }
+  }
+  if (t == 1023)
+  {
+    summary[0] = sums[t];
+    summary[1] = maxs[t];
+    summary[2] = extra_a != nullptr ? *extra_a : 0;
+    summary[3] = extra_b != nullptr ? *extra_b : 0;
+  }
+}
+
 inline unsigned int gridfor(uint64_t items)
 {
   return (unsigned int) ((items + VSA_BLOCK - 1) / VSA_BLOCK);
@@ -554,11 +646,16 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
                             dcount.as<unsigned long long>() + 1, 0ull,
                             nblocks, rocprim::plus<unsigned long long>(),
                             stream));
-    VSA_HIP(hipMemcpyAsync(&hsum, dcount.as<uint64_t>() + 1, 8,
-                           hipMemcpyDeviceToHost, stream));
-    VSA_HIP(hipMemcpyAsync(nmums, dcount.p, 8, hipMemcpyDeviceToHost,
-                           stream));
-    VSA_HIP(hipStreamSynchronize(stream));
+    {
+      const Fetch f[2] = {{dcount.p, 8}, {dcount.as<uint64_t>() + 1, 8}};
+      uint64_t got[2];
+      if (fetchwords(stream, f, 2, got))
+      {
+        return -100;
+      }
+      *nmums = got[0];
+      hsum = got[1];
+    }
     if (sumlength != nullptr)
     {
       *sumlength = hsum;
@@ -576,6 +673,103 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
   }
   VSA_HIP(hipMemcpyAsync(nmums, dcount.p, 8, hipMemcpyDeviceToHost, stream));
   VSA_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+// The filter of mumuniqueinquery on a packed candidate list: keys =
+// dbstart << lenbits | (2^lenbits - 1 - length), values = queryseq << 16 |
+// querystart (k_query_search with packbits).  One sort of the pairs, the
+// filter on the keys, and the surviving pairs become the records: the
+// candidates never exist as 32-byte records.
+int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
+                     unsigned int lenbits, unsigned int dbbits,
+                     hipStream_t stream, DevBuf &mums, uint64_t *nmums,
+                     uint64_t *sumlength)
+{
+  *nmums = 0;
+  *sumlength = 0;
+  if (ncand == 0)
+  {
+    return 0;
+  }
+  DevBuf k2, v2, ends, dbright, keep, slots, temp, dcount, blocksum;
+  const size_t nblocks = gridfor(ncand);
+  if (k2.alloc(ncand * 8) || v2.alloc(ncand * 8) || ends.alloc(ncand * 8) ||
+      dbright.alloc(ncand * 8) || keep.alloc(ncand) ||
+      slots.alloc(ncand * 4) || dcount.alloc(16) ||
+      blocksum.alloc(nblocks * 8) || mums.alloc(ncand * sizeof(vsa_match)))
+  {
+    return -100;
+  }
+  size_t tb = 0;
+  VSA_HIP(rocprim::radix_sort_pairs(
+      nullptr, tb, keys.as<uint64_t>(), k2.as<uint64_t>(),
+      vals.as<uint64_t>(), v2.as<uint64_t>(), (size_t) ncand, 0u,
+      lenbits + dbbits, stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::radix_sort_pairs(
+      temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<uint64_t>(),
+      v2.as<uint64_t>(), (size_t) ncand, 0u, lenbits + dbbits, stream));
+  k_mum_keyends<<<nblocks, VSA_BLOCK, 0, stream>>>(
+      k2.as<uint64_t>(), ncand, lenbits, ends.as<uint64_t>());
+  VSA_HIP(hipGetLastError());
+  tb = 0;
+  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
+                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  (size_t) ncand, rocprim::maximum<uint64_t>(),
+                                  stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
+                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  (size_t) ncand, rocprim::maximum<uint64_t>(),
+                                  stream));
+  k_mum_keyflags<<<nblocks, VSA_BLOCK, 0, stream>>>(
+      k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
+      lenbits, keep.as<uint8_t>());
+  VSA_HIP(hipGetLastError());
+  auto keepit =
+      rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
+  tb = 0;
+  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, keepit, slots.as<uint32_t>(),
+                                  (uint32_t) 0, (size_t) ncand,
+                                  rocprim::plus<uint32_t>(), stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
+                                  (uint32_t) 0, (size_t) ncand,
+                                  rocprim::plus<uint32_t>(), stream));
+  k_mum_writepacked<<<nblocks, VSA_BLOCK, 0, stream>>>(
+      k2.as<uint64_t>(), v2.as<uint64_t>(), keep.as<uint8_t>(),
+      slots.as<uint32_t>(), ncand, lenbits, mums.as<vsa_match>(),
+      dcount.as<uint64_t>(), blocksum.as<unsigned long long>());
+  VSA_HIP(hipGetLastError());
+  tb = 0;
+  VSA_HIP(rocprim::reduce(nullptr, tb, blocksum.as<unsigned long long>(),
+                          dcount.as<unsigned long long>() + 1, 0ull, nblocks,
+                          rocprim::plus<unsigned long long>(), stream));
+  if (temp.alloc(tb))
+  {
+    return -100;
+  }
+  VSA_HIP(rocprim::reduce(temp.p, tb, blocksum.as<unsigned long long>(),
+                          dcount.as<unsigned long long>() + 1, 0ull, nblocks,
+                          rocprim::plus<unsigned long long>(), stream));
+  const Fetch f[2] = {{dcount.p, 8}, {dcount.as<uint64_t>() + 1, 8}};
+  uint64_t got[2];
+  if (fetchwords(stream, f, 2, got))
+  {
+    return -100;
+  }
+  *nmums = got[0];
+  *sumlength = got[1];
   return 0;
 }
 
@@ -742,9 +936,13 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
                               rocprim::counting_iterator<uint32_t>(0),
                               wlist.as<uint32_t>(), wnlist.as<uint64_t>(),
                               (size_t) nq, wanted, stream));
-      VSA_HIP(hipMemcpyAsync(&nlist, wnlist.p, 8, hipMemcpyDeviceToHost,
-                             stream));
-      VSA_HIP(hipStreamSynchronize(stream));
+      {
+        const Fetch f = {wnlist.p, 8};
+        if (fetchwords(stream, &f, 1, &nlist))
+        {
+          return -100;
+        }
+      }
       if (nlist > 0)
       {
         if (deepok)
@@ -781,9 +979,13 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, widen, wbase.as<uint64_t>(),
                                     (uint64_t) 0, (size_t) (nq + 1),
                                     rocprim::plus<uint64_t>(), stream));
-    VSA_HIP(hipMemcpyAsync(&nwork, wbase.as<uint64_t>() + nq, 8,
-                           hipMemcpyDeviceToHost, stream));
-    VSA_HIP(hipStreamSynchronize(stream));
+    {
+      const Fetch f = {wbase.as<uint64_t>() + nq, 8};
+      if (fetchwords(stream, &f, 1, &nwork))
+      {
+        return -100;
+      }
+    }
     if (wlq.alloc(nwork * 4) || wloff.alloc(nwork * 4))
     {
       return -100;
@@ -811,11 +1013,34 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     firstpass = false; // the work reduction was not entered
   }
-  std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
-  DevBuf doff, rawout, rawkeys;
-  if (cursor.alloc(hcur.size() * 8) || doff.alloc(nshards * 8))
+  DevBuf doff, rawout, rawkeys, summary;
+  if (cursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
+      doff.alloc(nshards * 8) || summary.alloc(4 * 8))
   {
     return -100;
+  }
+  if (firstpass)
+  {
+    // slots of the first-pass candidates behind the kernel's matches:
+    // enqueued ahead of the search so that one read-back serves both
+    const uint64_t nq = queries->nq;
+    size_t tb = 0;
+    auto flag = rocprim::make_transform_iterator(wfmlen.as<uint32_t>(),
+                                                 NonZeroToU32());
+    if (wfslot.alloc(nq * 4))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, flag, wfslot.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) nq,
+                                    rocprim::plus<uint32_t>(), stream));
+    if (wtemp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, flag, wfslot.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) nq,
+                                    rocprim::plus<uint32_t>(), stream));
   }
   // first guess: MUM modes report at most one match per work-item but
   // typically about one per query; MEM is unbounded.  The kernel counts what
@@ -825,21 +1050,32 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       std::max<uint64_t>((queries->nq * 2 / nshards) * 5 / 4 + 64, 256);
   uint64_t needed = 0, maxshard = 0;
   double searchms = 0;
+  // -mum with the filter: candidates as (sort key, value) pairs, see
+  // mumfilter_packed
+  const unsigned int lenbits = bitsfor(queries->maxlength),
+                     dbbits = bitsfor(index->n);
+  const bool packed = domum && !domumcand && (index->tune & 16u) == 0 &&
+                      lenbits + dbbits <= 64 &&
+                      queries->maxlength < 0xFFFFu &&
+                      ((queries->nq + qs.seqoffset) >> 48) == 0;
+  const uint32_t packbits = packed ? lenbits : 0;
+  const size_t recsize = packed ? 8 : sizeof(vsa_match);
   for (int attempt = 0; attempt < 2; attempt++)
   {
-    if (rawout.alloc(nshards * shardcap * sizeof(vsa_match)) ||
+    if (rawout.alloc(nshards * shardcap * recsize) ||
         rawkeys.alloc(nshards * shardcap * 8))
     {
       return -100;
     }
-    VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
+    VSA_HIP(hipMemsetAsync(cursor.p, 0,
+                           (size_t) nshards * VSA_CURSOR_STRIDE * 8, stream));
     tsearch.start();
 #define VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, BLK)                              \
   k_query_search<IDX, MUMFLAG, KEYFLAG, BLK>                                  \
       <<<(unsigned int) ((nwork + BLK - 1) / BLK), BLK, 0, stream>>>(         \
           ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
-          nshards - 1, cursor.as<unsigned long long>())
+          nshards - 1, cursor.as<unsigned long long>(), packbits)
 #define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
   do                                                                          \
   {                                                                           \
@@ -887,18 +1123,28 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
 #undef VSA_LAUNCH_QUERY_B
     tsearch.stop();
     VSA_HIP(hipGetLastError());
-    VSA_HIP(hipMemcpyAsync(hcur.data(), cursor.p, hcur.size() * 8,
-                           hipMemcpyDeviceToHost, stream));
-    VSA_HIP(hipStreamSynchronize(stream));
-    searchms += tsearch.ms();
-    needed = maxshard = 0;
-    for (uint32_t sh = 0; sh < nshards; sh++)
+    // where each region goes in the dense list, how much there is
+    k_shard_summary<<<1, 1024, 0, stream>>>(
+        cursor.as<unsigned long long>(), nshards, doff.as<uint64_t>(),
+        firstpass ? wfslot.as<uint32_t>() + queries->nq - 1 : nullptr,
+        firstpass ? wfmlen.as<uint32_t>() + queries->nq - 1 : nullptr,
+        summary.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
     {
-      const uint64_t cnt = hcur[(uint64_t) sh * VSA_CURSOR_STRIDE];
-      hoff[sh] = needed;
-      needed += cnt;
-      maxshard = std::max(maxshard, cnt);
+      const Fetch f[4] = {{summary.as<uint64_t>(), 8},
+                          {summary.as<uint64_t>() + 1, 8},
+                          {summary.as<uint64_t>() + 2, 8},
+                          {summary.as<uint64_t>() + 3, 8}};
+      uint64_t got[4];
+      if (fetchwords(stream, f, 4, got))
+      {
+        return -100;
+      }
+      needed = got[0];
+      maxshard = got[1];
+      nfirst = firstpass ? got[2] + (got[3] != 0 ? 1 : 0) : 0;
     }
+    searchms += tsearch.ms();
     if (maxshard <= shardcap)
     {
       break;
@@ -911,47 +1157,23 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
               (unsigned long long) maxshard, (unsigned long long) shardcap);
     return -5;
   }
-  if (firstpass)
-  {
-    // slots of the first-pass candidates behind the kernel's matches
-    const uint64_t nq = queries->nq;
-    size_t tb = 0;
-    uint32_t lastslot = 0, lastlen = 0;
-    auto flag = rocprim::make_transform_iterator(wfmlen.as<uint32_t>(),
-                                                 NonZeroToU32());
-    if (wfslot.alloc(nq * 4))
-    {
-      return -100;
-    }
-    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, flag, wfslot.as<uint32_t>(),
-                                    (uint32_t) 0, (size_t) nq,
-                                    rocprim::plus<uint32_t>(), stream));
-    if (wtemp.alloc(tb))
-    {
-      return -100;
-    }
-    VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, flag, wfslot.as<uint32_t>(),
-                                    (uint32_t) 0, (size_t) nq,
-                                    rocprim::plus<uint32_t>(), stream));
-    VSA_HIP(hipMemcpyAsync(&lastslot, wfslot.as<uint32_t>() + nq - 1, 4,
-                           hipMemcpyDeviceToHost, stream));
-    VSA_HIP(hipMemcpyAsync(&lastlen, wfmlen.as<uint32_t>() + nq - 1, 4,
-                           hipMemcpyDeviceToHost, stream));
-    VSA_HIP(hipStreamSynchronize(stream));
-    nfirst = (uint64_t) lastslot + (lastlen != 0 ? 1 : 0);
-  }
   if (needed + nfirst > 0)
   {
-    if (out.alloc((needed + nfirst) * sizeof(vsa_match)) ||
+    if (out.alloc((needed + nfirst) * recsize) ||
         keys.alloc((needed + nfirst) * 8))
     {
       return -100;
     }
-    if (needed > 0)
+    if (needed > 0 && packed)
     {
-      VSA_HIP(hipMemcpyAsync(doff.p, hoff.data(), nshards * 8,
-                             hipMemcpyHostToDevice, stream));
-      k_compact_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
+      k_compact_shards<uint64_t><<<nshards, VSA_BLOCK, 0, stream>>>(
+          rawout.as<uint64_t>(), rawkeys.as<uint64_t>(), shardcap,
+          cursor.as<unsigned long long>(), doff.as<uint64_t>(),
+          out.as<uint64_t>(), keys.as<uint64_t>());
+      VSA_HIP(hipGetLastError());
+    } else if (needed > 0)
+    {
+      k_compact_shards<vsa_match><<<nshards, VSA_BLOCK, 0, stream>>>(
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
           cursor.as<unsigned long long>(), doff.as<uint64_t>(),
           out.as<vsa_match>(), keys.as<uint64_t>());
@@ -963,7 +1185,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
           wfslot.as<uint32_t>(), queries->nq, perquery, dbase, qs.seqoffset,
           needed,
-          out.as<vsa_match>(), keys.as<uint64_t>());
+          out.as<vsa_match>(), keys.as<uint64_t>(), packbits);
       VSA_HIP(hipGetLastError());
     }
     needed += nfirst;
@@ -973,8 +1195,15 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     DevBuf mums;
     uint64_t nm = 0;
-    if (mumuniqueinquery(out, needed, stream, mums, &nm, 0, nullptr,
-                         index->n, queries->maxlength, &mumsum))
+    if (packed)
+    {
+      if (mumfilter_packed(keys, out, needed, lenbits, dbbits, stream, mums,
+                           &nm, &mumsum))
+      {
+        return -100;
+      }
+    } else if (mumuniqueinquery(out, needed, stream, mums, &nm, 0, nullptr,
+                                index->n, queries->maxlength, &mumsum))
     {
       return -100;
     }
@@ -1057,7 +1286,6 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
       std::min<uint64_t>((ntiles + wavesperblock - 1) / wavesperblock,
                          (uint64_t) vsa_peakblocks());
   const uint32_t slmin = (uint32_t) (searchlength < 255 ? searchlength : 255);
-  std::vector<uint64_t> hcur(nshards * VSA_CURSOR_STRIDE), hoff(nshards);
   DevBuf cursor, doff, rawpos, peaks, sorted, temp, cand, keep, dcount, mums;
   uint64_t shardcap = std::max<uint64_t>(n / 64 / nshards + 1024, 4096),
            needed = 0, maxshard = 0;
@@ -1069,8 +1297,9 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     VSA_ERROR("self-index MUM scan: texts beyond 2^32 are not supported");
     return -3;
   }
-  if (cursor.alloc(hcur.size() * 8) || doff.alloc(nshards * 8) ||
-      dcount.alloc(8))
+  DevBuf summary;
+  if (cursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
+      doff.alloc(nshards * 8) || dcount.alloc(8) || summary.alloc(4 * 8))
   {
     return -100;
   }
@@ -1081,7 +1310,8 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     {
       return -100;
     }
-    VSA_HIP(hipMemsetAsync(cursor.p, 0, hcur.size() * 8, stream));
+    VSA_HIP(hipMemsetAsync(cursor.p, 0,
+                           (size_t) nshards * VSA_CURSOR_STRIDE * 8, stream));
     tsearch.start();
 #define VSA_PEAKS(PIECES, NT)                                                 \
   k_selfmum_peaks<PIECES, NT><<<(unsigned int) nblocks, VSA_BLOCK, 0,         \
@@ -1098,18 +1328,22 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
 #undef VSA_PEAKS
     tsearch.stop();
     VSA_HIP(hipGetLastError());
-    VSA_HIP(hipMemcpyAsync(hcur.data(), cursor.p, hcur.size() * 8,
-                           hipMemcpyDeviceToHost, stream));
-    VSA_HIP(hipStreamSynchronize(stream));
-    searchms = tsearch.ms(); // the streaming pass (of the last attempt)
-    needed = maxshard = 0;
-    for (uint32_t sh = 0; sh < nshards; sh++)
+    k_shard_summary<<<1, 1024, 0, stream>>>(
+        cursor.as<unsigned long long>(), nshards, doff.as<uint64_t>(),
+        nullptr, nullptr, summary.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
     {
-      const uint64_t cnt = hcur[(uint64_t) sh * VSA_CURSOR_STRIDE];
-      hoff[sh] = needed;
-      needed += cnt;
-      maxshard = std::max(maxshard, cnt);
+      const Fetch f[2] = {{summary.as<uint64_t>(), 8},
+                          {summary.as<uint64_t>() + 1, 8}};
+      uint64_t got[2];
+      if (fetchwords(stream, f, 2, got))
+      {
+        return -100;
+      }
+      needed = got[0];
+      maxshard = got[1];
     }
+    searchms = tsearch.ms(); // the streaming pass (of the last attempt)
     if (maxshard <= shardcap)
     {
       break;
@@ -1130,8 +1364,6 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     {
       return -100;
     }
-    VSA_HIP(hipMemcpyAsync(doff.p, hoff.data(), nshards * 8,
-                           hipMemcpyHostToDevice, stream));
     k_gather_u32_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
         rawpos.as<uint32_t>(), shardcap, cursor.as<unsigned long long>(),
         doff.as<uint64_t>(), peaks.as<uint32_t>());
@@ -1157,7 +1389,13 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     {
       return -100;
     }
-    VSA_HIP(hipMemcpyAsync(&nm, dcount.p, 8, hipMemcpyDeviceToHost, stream));
+    {
+      const Fetch f = {dcount.p, 8};
+      if (fetchwords(stream, &f, 1, &nm))
+      {
+        return -100;
+      }
+    }
     VSA_HIP(hipStreamSynchronize(stream));
     res->count = nm;
     res->matches = (vsa_match *) mums.release();
