@@ -338,6 +338,20 @@ int vsa_findsupermaximalrepeats(const vsa_index *index, uint64_t searchlength,
                                 vsa_result **result);
 
 /*
+  findtandems (Vmengine/ftandem.c:261-304), vmatch -tandem -l L IDX: right
+  branching tandem repeats -- every position v where a string of length
+  d >= L that names an lcp-interval occurs twice in a row and the repeat
+  cannot be shifted right by one symbol.  A match is (d, v, v + d, 0), laid
+  out like the other self matches.  Order: the lcp-intervals as the
+  reference's bottom-up traversal completes them, the repeats of one interval
+  from the reference's witness leftwards, then rightwards.  An index that
+  holds queries is the reference's error "tandem repeat search does not allow
+  query files in index" (ftandem.c:271-275).  Needs tis, suf, lcp (llv).
+*/
+int vsa_findtandems(const vsa_index *index, uint64_t searchlength,
+                    vsa_result **result);
+
+/*
   findmaximaluniquematches (Vmengine/fmumself.c:10-66): MUMs between the
   database and the query part of one index.  Reported like the reference's
   Outputfunction(outinfo, len, start1, start2): length, dbstart = start1,
@@ -397,6 +411,8 @@ int vsa_findsupermaximalrepeats_cb(const vsa_index *index,
                                    vsa_processmatch processmatch, void *info);
 int vsa_findmaximalrepeats_cb(const vsa_index *index, uint64_t searchlength,
                               vsa_processmatch processmatch, void *info);
+int vsa_findtandems_cb(const vsa_index *index, uint64_t searchlength,
+                       vsa_processmatch processmatch, void *info);
 
 /* ---- synthetic inputs (bench.py, tests): SURVEY.md section 8d ---------- */
 

@@ -514,3 +514,69 @@ WRAPMAXOUT(4)
 WRAPMAXOUT(12)
 WRAPMAXOUT(21)
 WRAPMAXOUT(31)
+
+/* ---- vmatch -tandem -l L IDX ---------------------------------------------- */
+
+/* findtandems (Vmengine/ftandem.c:261-304) builds a Matchstate and hands
+   every repeat to processfinal (OUTTANDEM :34-42): the same here */
+Sint __real_findtandems(Virtualtree *, Matchparam *, Bestflag, Uint, Uint,
+                        SelectBundle *, void *, Processfinalfunction,
+                        Evalues *, BOOL);
+
+static int tandemsink(void *info, const vsa_match *m)
+{
+  Matchstate *matchstate = (Matchstate *) info;
+  Match match;
+
+  match.distance = 0;
+  match.flag = 0;
+  match.seqnum2 = UNDEFSEQNUM2(&matchstate->virtualtree->multiseq);
+  match.length1 = match.length2 = (Uint) m->length;
+  match.position1 = (Uint) m->dbstart;
+  match.position2 = (Uint) m->queryseq;
+  return matchstate->processfinal(matchstate, &match) != 0 ? 1 : 0;
+}
+
+Sint __wrap_findtandems(Virtualtree *virtualtree, Matchparam *matchparam,
+                        Bestflag bestflag, Uint shownoevalue,
+                        Uint showselfpalindromic, SelectBundle *selectbundle,
+                        void *procmultiseq, Processfinalfunction processfinal,
+                        Evalues *evalues, BOOL domatchbuffering)
+{
+  Matchstate matchstate;
+  vsa_index *index;
+  int rc;
+
+  if (!usegpu() || virtualtree->suftab == NULL ||
+      virtualtree->lcptab == NULL ||
+      virtualtree->multiseq.sequence == NULL ||
+      HASINDEXEDQUERIES(&virtualtree->multiseq))
+  {
+    return __real_findtandems(virtualtree, matchparam, bestflag, shownoevalue,
+                              showselfpalindromic, selectbundle, procmultiseq,
+                              processfinal, evalues, domatchbuffering);
+  }
+  if (initMatchstate(&matchstate, virtualtree, NULL, matchparam, bestflag,
+                     shownoevalue, showselfpalindromic, selectbundle, 0,
+                     procmultiseq, DirectionForward, False, processfinal,
+                     evalues, domatchbuffering) != 0)
+  {
+    return (Sint) -1;
+  }
+  if (getgpuindex(virtualtree, 0, &index) != 0)
+  {
+    return (Sint) -1;
+  }
+  rc = vsa_findtandems_cb(index, matchparam->userdefinedleastlength,
+                          tandemsink, &matchstate);
+  trace("tandem repeats");
+  if (rc != 0)
+  {
+    if (rc != -1)
+    {
+      (void) gpufail();
+    }
+    return (Sint) -2;
+  }
+  return 0;
+}

@@ -144,6 +144,11 @@ int orc_findsupermax(const orc_index *idx, uint64_t searchlength,
    Vmengine/vmatfind.c:330-541 in the reference's order. */
 int orc_findmaximalrepeats(const orc_index *idx, uint64_t searchlength,
                            orc_matches *out, char *err);
+/* vmatch -tandem -l L IDX, right branching tandem repeats (oracle/vsself.c):
+   Vmengine/ftandem.c:24-304 in the reference's order.  length, dbstart =
+   start of the repeat, queryseq = dbstart + length, querystart 0. */
+int orc_findtandems(const orc_index *idx, uint64_t searchlength,
+                    orc_matches *out, char *err);
 uint64_t orc_getoptsplit(int doedist, uint64_t spliterrorbound,
                          uint64_t numofchars, uint64_t textlen,
                          uint64_t patternlength, uint64_t threshold);

@@ -416,3 +416,248 @@ int orc_findmaximalrepeats(const orc_index *ix, uint64_t searchlength,
 #undef NEEDSLOT
   return 0;
 }
+
+/*
+  Right branching tandem repeats, vmatch -tandem -l L IDX:
+    findtandems / processcompletenode / processsmallinterval /
+    tandemleftright                      Vmengine/ftandem.c:24-304
+    the depth first traversal            include/vdfstrav.c:247-420
+    findmaxprefixlen                     kurtz/findmaxpref.gen:1-96
+
+  Every lcp-interval [left, right] of depth d >= L is handed over when the
+  traversal completes it (children first, left to right).  Two suffixes: a
+  tandem if one starts d symbols behind the other (CHECKPAIR :60-71).  More:
+  the suffixes below the node that begin with the node's string twice are
+  looked up with one call of findmaxprefixlen (query = the text d symbols in
+  front of suf[left], of which the first d count as matched, :235-241) and
+  enumerated from the witness, first to the left, then to the right
+  (tandemleftright :105-186).  A repeat of length d at v is reported unless
+  the symbol behind it equals the one at v and both are regular -- then it
+  shifts right and is reported there (SHOWTANDEM :44-58, PROCESSSUFFIX
+  :73-88).  length = d, dbstart = v, queryseq = v + d, querystart = 0.
+*/
+typedef struct
+{
+  uint64_t depth, left;
+} Tnode;
+
+static void tandemout(const orc_index *ix, uint64_t d, uint64_t v, uint64_t w,
+                      orc_matches *out)
+{
+  /* SHOWTANDEM(v, w) with w = v + d; PROCESSSUFFIX with w = v + d too */
+  if (w + d == ix->n)
+  {
+    orc_push_match(out, d, v, v + d, 0);
+  } else
+  {
+    const uint8_t c1 = ix->tis[v], c2 = ix->tis[w + d];
+    if (c1 != c2 || ORC_ISSPECIAL(c1) || ORC_ISSPECIAL(c2))
+    {
+      orc_push_match(out, d, v, v + d, 0);
+    }
+  }
+}
+
+/* COMPARE of kurtz/maxpref.c:30-65 for a query that is the text at qpos */
+static int tcompare(const orc_index *ix, uint64_t sufstart, int64_t qpos,
+                    uint64_t querylen, uint64_t *lcplen)
+{
+  uint64_t l = *lcplen;
+  int ret;
+
+  for (;; l++)
+  {
+    uint8_t q;
+    if (l >= querylen)
+    {
+      ret = 0;
+      break;
+    }
+    if (sufstart + l >= ix->n)
+    {
+      ret = -1;
+      break;
+    }
+    q = ix->tis[qpos + (int64_t) l];
+    ret = (int) q - (int) ix->tis[sufstart + l];
+    if (ret == 0)
+    {
+      if (ORC_ISSPECIAL(q))
+      {
+        ret = -1;
+        break;
+      }
+    } else
+    {
+      break;
+    }
+  }
+  *lcplen = l;
+  return ret;
+}
+
+static void tfindmaxprefixlen(const orc_index *ix, uint64_t vleft,
+                              uint64_t vright, uint64_t offset, int64_t qpos,
+                              uint64_t querylen, uint64_t *maxlcp,
+                              uint64_t *witness)
+{
+  uint64_t left, right, mid, lcplen, lpref, rpref;
+  int ret;
+
+  lcplen = offset;
+  ret = tcompare(ix, sufat(ix, vleft), qpos, querylen, &lcplen);
+  *maxlcp = lcplen;
+  *witness = vleft;
+  if (ret <= 0)
+  {
+    return;
+  }
+  lpref = lcplen;
+  lcplen = offset;
+  ret = tcompare(ix, sufat(ix, vright), qpos, querylen, &lcplen);
+  rpref = lcplen;
+  if (lpref < rpref)
+  {
+    *maxlcp = rpref;
+    *witness = vright;
+    lcplen = lpref;
+  } else
+  {
+    *maxlcp = lpref;
+    *witness = vleft;
+  }
+  if (ret >= 0 || *maxlcp >= querylen)
+  {
+    return;
+  }
+  left = vleft;
+  right = vright;
+  while (right > left + 1)
+  {
+    mid = (left + right) / 2;
+    ret = tcompare(ix, sufat(ix, mid), qpos, querylen, &lcplen);
+    if (*maxlcp < lcplen)
+    {
+      *maxlcp = lcplen;
+      *witness = mid;
+    }
+    if (ret < 0)
+    {
+      rpref = lcplen;
+      if (lpref < rpref)
+      {
+        lcplen = lpref;
+      }
+      right = mid;
+    } else if (ret > 0)
+    {
+      lpref = lcplen;
+      if (rpref < lpref)
+      {
+        lcplen = rpref;
+      }
+      left = mid;
+    } else
+    {
+      break;
+    }
+  }
+}
+
+static void tandemnode(const orc_index *ix, uint64_t d, uint64_t left,
+                       uint64_t right, orc_matches *out)
+{
+  if (right - left + 1 <= 2)
+  {
+    const uint64_t s0 = sufat(ix, left), s1 = sufat(ix, left + 1);
+    if (s0 + d == s1)
+    {
+      tandemout(ix, d, s0, s1, out);
+    } else if (s1 + d == s0)
+    {
+      tandemout(ix, d, s1, s0, out);
+    }
+  } else
+  {
+    uint64_t maxlcp, witness, ind;
+    tfindmaxprefixlen(ix, left, right, d,
+                      (int64_t) sufat(ix, left) - (int64_t) d, 2 * d, &maxlcp,
+                      &witness);
+    if (maxlcp != 2 * d)
+    {
+      return;
+    }
+    for (ind = witness;; ind--)
+    {
+      const uint64_t s = sufat(ix, ind);
+      tandemout(ix, d, s, s + d, out);
+      if (ind == 0 || lcpat(ix, ind) < 2 * d)
+      {
+        break;
+      }
+    }
+    for (ind = witness + 1;; ind++)
+    {
+      uint64_t s;
+      if (ind > ix->n || lcpat(ix, ind) < 2 * d)
+      {
+        break;
+      }
+      s = sufat(ix, ind);
+      tandemout(ix, d, s, s + d, out);
+    }
+  }
+}
+
+int orc_findtandems(const orc_index *ix, uint64_t searchlength,
+                    orc_matches *out, char *err)
+{
+  Tnode *stack = NULL;
+  uint64_t allocated = 0, top = 0, c;
+
+  if (ix->hasqueries)
+  {
+    snprintf(err, 256,
+             "tandem repeat search does not allow query files in index");
+    return -1;
+  }
+  if (searchlength == 0)
+  {
+    snprintf(err, 256, "tandem repeat search needs a length >= 1");
+    return -1;
+  }
+  allocated = 64;
+  stack = (Tnode *) malloc(allocated * sizeof(Tnode));
+  stack[0].depth = 0;
+  stack[0].left = 0;
+  top = 1;
+  for (c = 0; c + 1 <= ix->n; c++) /* lcp[c+1] decides what happens behind c */
+  {
+    const uint64_t currentlcp = lcpat(ix, c + 1);
+    uint64_t newleft = c; /* a leaf edge becomes the first child */
+
+    while (currentlcp < stack[top - 1].depth)
+    {
+      if (stack[top - 1].depth >= searchlength)
+      {
+        tandemnode(ix, stack[top - 1].depth, stack[top - 1].left, c, out);
+      }
+      newleft = stack[top - 1].left; /* the finished subtree is the child */
+      top--;
+    }
+    if (currentlcp > stack[top - 1].depth)
+    {
+      if (top == allocated)
+      {
+        allocated *= 2;
+        stack = (Tnode *) realloc(stack, allocated * sizeof(Tnode));
+      }
+      stack[top].depth = currentlcp;
+      stack[top].left = newleft;
+      top++;
+    }
+  }
+  /* what is left has depth 0 (lcp[n] = 0): below every L */
+  free(stack);
+  return 0;
+}

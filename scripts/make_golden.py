@@ -120,6 +120,8 @@ def main():
                ["-qspeedup", str(sp), "-p", "-l", "30", "ychrIII.fna"], wd)
     record(case, "repeats_dp40", ["-d", "-p", "-l", "40", "ychrIII.fna"], wd,
            both=True)
+    # right branching tandem repeats (Vmengine/ftandem.c)
+    record(case, "tandem8", ["-tandem", "-l", "8", "ychrIII.fna"], wd)
     shutil.rmtree(wd)
 
     # ---- 2. micro: multi-FASTA, wildcards, prefixlength 1 ----------------
@@ -151,6 +153,8 @@ def main():
                                    "db.fna"], wd)
     record(case, "supermax2", ["-supermax", "-l", "2", "db.fna"], wd)
     record(case, "repeats2", ["-l", "2", "db.fna"], wd)
+    for L in (1, 2):
+        record(case, "tandem%d" % L, ["-tandem", "-l", str(L), "db.fna"], wd)
     shutil.rmtree(wd)
 
     # ---- 3. Wildcards.fna of the reference's test data --------------------
@@ -195,6 +199,7 @@ def main():
     record(case, "mem8_short", ["-l", "8", "-q", "short.fna", dbf], wd)
     record(case, "supermax12", ["-supermax", "-l", "12", dbf], wd)
     record(case, "repeats12", ["-l", "12", dbf], wd)
+    record(case, "tandem3", ["-tandem", "-l", "3", dbf], wd)
     # queries inside the index (Mum.sh:35-61): vmatch -mum on db+query index
     manifest["grumbach_all"] = {"db": [dbf + ".gz"], "indexedquery":
                                 [qf + ".gz"], "runs": {}}
@@ -304,6 +309,30 @@ def main():
     record(case, "complete", ["-complete", "-q", "reads.fna", "db.fna"], wd)
     record(case, "supermax20", ["-supermax", "-l", "20", "db.fna"], wd)
     record(case, "repeats25", ["-l", "25", "db.fna"], wd)
+    record(case, "tandem4", ["-tandem", "-l", "4", "db.fna"], wd)
+    shutil.rmtree(wd)
+
+    # ---- 7. the reference's tandem repeat test (src/Vmatch/Checktandem.sh):
+    # index of src/testdata/at1MB built as src/bin/Makeindex.sh does, vmatch
+    # -l 40 -tandem against the known answer src/Vmatch/Testdir/Tandem40AT
+    wd = tempfile.mkdtemp()
+    case = "at1mb"
+    shutil.copy(REFSRC + "/testdata/at1MB", wd + "/at1MB")
+    gzcopy(wd + "/at1MB", GOLD + "/at1MB.gz")
+    shutil.copy(REFSRC + "/Vmatch/Testdir/Tandem40AT", GOLD + "/Tandem40AT")
+    manifest[case] = {"db": ["at1MB.gz"], "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "atindex", ["-indexname", "atindex", "-db", "at1MB", "-pl",
+                        "-dna", "-bwt", "-lcp", "-suf", "-ois", "-tis",
+                        "-bck", "-sti1"])
+    for L in (40, 12, 5):
+        record(case, "tandem%d" % L, ["-tandem", "-l", str(L), "atindex"],
+               wd)
+    rc, lines, err = run_case(wd, ["-l", "40", "-tandem", "atindex"])
+    known = [l for l in open(GOLD + "/Tandem40AT").read().splitlines()
+             if l and not l.startswith("#")]
+    assert lines == known, "the reference does not reproduce Tandem40AT"
+    record(case, "supermax40", ["-supermax", "-l", "40", "atindex"], wd)
     shutil.rmtree(wd)
 
     np.savez_compressed(GOLD + "/expected.npz", **arrays)

@@ -95,6 +95,9 @@ def oracle_lib():
         lib.orc_findmaximalrepeats.argtypes = [
             C.POINTER(OrcIndex), C.c_uint64, C.POINTER(OrcMatches),
             C.c_char_p]
+        lib.orc_findtandems.argtypes = [
+            C.POINTER(OrcIndex), C.c_uint64, C.POINTER(OrcMatches),
+            C.c_char_p]
         lib.orc_getoptsplit.argtypes = [C.c_int] + [C.c_uint64] * 5
         lib.orc_getoptsplit.restype = C.c_uint64
         lib.orc_mumuniqueinquery.argtypes = [C.c_void_p, C.c_uint64,
@@ -279,6 +282,20 @@ def oracle_repeats(index, searchlength):
     oi = index.orc()
     rc = lib.orc_findmaximalrepeats(C.byref(oi), int(searchlength),
                                     C.byref(out), err)
+    res = _take(out)
+    if rc != 0:
+        raise OracleError(err.value.decode())
+    return res
+
+
+def oracle_tandems(index, searchlength):
+    """vmatch -tandem -l L IDX: (length, start, start + length, 0)"""
+    lib = oracle_lib()
+    out, err = OrcMatches(), C.create_string_buffer(512)
+    lib.orc_matches_init(C.byref(out))
+    oi = index.orc()
+    rc = lib.orc_findtandems(C.byref(oi), int(searchlength), C.byref(out),
+                             err)
     res = _take(out)
     if rc != 0:
         raise OracleError(err.value.decode())

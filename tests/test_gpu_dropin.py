@@ -57,7 +57,8 @@ MKV = {"largepat": ["-db", "ychrIII.fna"], "micro": ["-db", "db.fna"],
        "grumbach": ["-db", "humhbb.fna"],
        "grumbach_all": ["-indexname", "all", "-db", "humhbb.fna", "-q",
                         "humdystrop.fna"],
-       "c1": ["-db", "genome.fna"], "c5": ["-db", "db.fna"]}
+       "c1": ["-db", "genome.fna"], "c5": ["-db", "db.fna"],
+       "at1mb": ["-indexname", "atindex", "-db", "at1MB"]}
 
 
 def run_gpu_vmatch(args, wd, env=None):

@@ -37,6 +37,9 @@ def run_gpu(V, case, key, bits=64):
     if key.startswith("supermax"):
         r = V.findsupermaximalrepeats(gi, int(key[len("supermax"):]))
         return H.repeats_as_ref(idx, r.fetch())
+    if key.startswith("tandem"):
+        r = V.findtandems(gi, int(key[len("tandem"):]))
+        return H.repeats_as_ref(idx, r.fetch())
     if key.startswith("palindromic"):
         rq = H.index_as_rc_queries(idx)
         L = int(key[len("palindromic"):].partition("_sp")[0])
@@ -548,6 +551,9 @@ def test_wide_device_tables(V, case, monkeypatch):
         elif key.startswith("supermax"):
             got = H.repeats_as_ref(idx, V.findsupermaximalrepeats(
                 gi, int(key[len("supermax"):])).fetch())
+        elif key.startswith("tandem"):
+            got = H.repeats_as_ref(idx, V.findtandems(
+                gi, int(key[len("tandem"):])).fetch())
         elif key.startswith("repeats"):
             conv = (H.selfmatches_as_ref if idx.hasqueries
                     else H.repeats_as_ref)
@@ -702,3 +708,75 @@ def test_unordered_candidates_and_partition_by_index_range(V):
                                               counts.astype(np.int64)))
         assert np.array_equal(np.sort(got, order=list(got.dtype.names)),
                               np.sort(ordered, order=list(ordered.dtype.names)))
+
+
+def test_tandem_repeats_on_texts_full_of_them(V):
+    """short and long units, runs of one symbol (nested intervals with many
+    suffixes), copies of tandem arrays, wildcards and separators inside and
+    behind arrays, an array at the very end of the text"""
+    rng = np.random.default_rng(4711)
+    for trial in range(6):
+        seqs = []
+        for s in range(int(rng.integers(1, 4))):
+            parts, total = [], 0
+            while total < 3000:
+                k = rng.random()
+                if k < 0.45:
+                    unit = rng.integers(0, 4, int(rng.integers(1, 15)))
+                    piece = np.tile(unit, int(rng.integers(2, 9)))
+                elif k < 0.5:
+                    piece = np.full(int(rng.integers(1, 3)), H.WILDCARD)
+                elif k < 0.6 and parts:
+                    piece = parts[int(rng.integers(0, len(parts)))]
+                elif k < 0.65:
+                    piece = np.full(int(rng.integers(5, 70)),
+                                    int(rng.integers(0, 4)))
+                else:
+                    piece = rng.integers(0, 4, int(rng.integers(1, 40)))
+                parts.append(piece.astype(np.uint8))
+                total += len(piece)
+            seqs.append(np.concatenate(parts))
+        if trial % 2:
+            unit = rng.integers(0, 4, 7).astype(np.uint8)
+            seqs[-1] = np.concatenate([seqs[-1], np.tile(unit, 5)])
+        tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
+                              for s in seqs])[:-1].astype(np.uint8)
+        gi = V.Index.build(tis, 4, 0)
+        t = gi.download()
+        host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"],
+                       t["suf"], t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+        for L in (1, 2, 3, 5, 8, 13, 30):
+            got = V.findtandems(gi, L).fetch()
+            want = H.oracle_tandems(host, L)
+            assert np.array_equal(got, want), (trial, L)
+            if L == 1:
+                assert len(want) > 100
+
+
+def test_tandem_repeats_with_units_beyond_255(V):
+    """interval depths >= 255 come from the exception table llv"""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, 300).astype(np.uint8)
+    tis = np.concatenate([rng.integers(0, 4, 500), unit, unit, unit[:120],
+                          rng.integers(0, 4, 400), unit, unit,
+                          rng.integers(0, 4, 100)]).astype(np.uint8)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    for L in (100, 255, 256, 300, 301):
+        got = V.findtandems(gi, L).fetch()
+        want = H.oracle_tandems(host, L)
+        assert np.array_equal(got, want), L
+    assert len(H.oracle_tandems(host, 300)) >= 2
+
+
+def test_tandem_repeats_errors_and_empty_results(V):
+    gi = gpu_index(V, "grumbach_all")
+    with pytest.raises(V.VsaError) as ei:
+        V.findtandems(gi, 14)
+    assert "does not allow query files in index" in str(ei.value)
+    gi = gpu_index(V, "c1")
+    assert V.findtandems(gi, 10 ** 6).count == 0
+    with pytest.raises(V.VsaError):
+        V.findtandems(gi, 0)

@@ -43,6 +43,9 @@ def run_oracle(case, key):
     if key.startswith("supermax"):
         L = int(key[len("supermax"):])
         return H.repeats_as_ref(idx, H.oracle_supermax(idx, L)), None
+    if key.startswith("tandem"):
+        L = int(key[len("tandem"):])
+        return H.repeats_as_ref(idx, H.oracle_tandems(idx, L)), None
     name, _, sp = key.partition("_sp")
     sp = int(sp) if sp else 2
     if name.startswith("mumcand"):
@@ -190,3 +193,24 @@ def test_live_reference_on_fresh_random_input(tmp_path):
         assert rc == 0, err
         assert np.array_equal(H.parse_vmatch_lines(lines),
                               H.matches_as_ref(idx, fn())), args
+
+
+def test_tandem_known_answer_of_the_reference():
+    """src/Vmatch/Checktandem.sh: vmatch -l 40 -tandem on the index of
+    src/testdata/at1MB must print src/Vmatch/Testdir/Tandem40AT (stored as it
+    is): the oracle reproduces the file, order included"""
+    known = [l for l in open(os.path.join(H.GOLDEN, "Tandem40AT"))
+             .read().splitlines() if l and not l.startswith("#")]
+    want = H.parse_vmatch_lines(known)
+    assert len(want) == 8
+    idx, _ = H.load_case("at1mb")
+    got = H.repeats_as_ref(idx, H.oracle_tandems(idx, 40))
+    assert np.array_equal(got, want)
+    assert np.array_equal(want, H.expected("at1mb", "tandem40"))
+
+
+def test_tandem_oracle_refuses_an_index_with_queries():
+    idx, _ = H.load_case("grumbach_all")
+    with pytest.raises(H.OracleError) as ei:
+        H.oracle_tandems(idx, 14)
+    assert "does not allow query files in index" in str(ei.value)

@@ -75,7 +75,7 @@ def test_sink_prints_what_vmatch_printed(case, key):
         sink = V.Sink(V.SINK_QUERY, idx.n, idx.ssp, 4, rq.start, rq.length,
                       idx.n, leastlength=30, palindromic=True,
                       selfpalindromic=True)
-    elif key.startswith("supermax") or key.startswith("repeats"):
+    elif key.startswith(("supermax", "repeats", "tandem")):
         starts = np.concatenate(([0], idx.ssp + 1)).astype(np.uint64)
         m = records(idx, exp)
         m["queryseq"] = starts[exp["queryseq"].astype(np.int64)] + \

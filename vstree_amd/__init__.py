@@ -145,6 +145,8 @@ def _load():
         "vsa_findmaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findsupermaximalrepeats": (I, [V, U64, PP]),
         "vsa_findsupermaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
+        "vsa_findtandems": (I, [V, U64, PP]),
+        "vsa_findtandems_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
         "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
         "vsa_findmaximaluniquematches_cb": (I, [V, U64, PROCESSMATCH, V]),
@@ -430,6 +432,13 @@ def findsupermaximalrepeats(index, searchlength):
     h = C.c_void_p()
     _check(lib.vsa_findsupermaximalrepeats(index._h, int(searchlength),
                                            C.byref(h)))
+    return Result(h)
+
+
+def findtandems(index, searchlength):
+    """vmatch -tandem -l L IDX (Vmengine/ftandem.c:261)."""
+    h = C.c_void_p()
+    _check(lib.vsa_findtandems(index._h, int(searchlength), C.byref(h)))
     return Result(h)
 
 

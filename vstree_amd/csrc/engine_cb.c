@@ -119,3 +119,12 @@ int vsa_findmaximalrepeats_cb(const vsa_index *index, uint64_t searchlength,
 
   return replay(result, rc, processmatch, info);
 }
+
+int vsa_findtandems_cb(const vsa_index *index, uint64_t searchlength,
+                       vsa_processmatch processmatch, void *info)
+{
+  vsa_result *result = NULL;
+  int rc = vsa_findtandems(index, searchlength, &result);
+
+  return replay(result, rc, processmatch, info);
+}

@@ -21,7 +21,8 @@
 //                            over lcptab + bwttab for indexes that hold
 //                            their queries (Vmengine/fmumself.c:10-66)
 //   approx_search.inc    A   approximate complete matches (-complete -e/-h)
-//   selfmatch_search.inc R,S maximal and supermaximal repeats of the index
+//   selfmatch_search.inc R,S,T maximal / supermaximal / tandem repeats of the
+//                          index
 //
 // rocPRIM supplies radix sort / scan / reduce only.
 //
@@ -2106,6 +2107,49 @@ extern "C" int vsa_findsupermaximalrepeats(const vsa_index *index,
   const int rc = (index->isize == 4)
                      ? run_supermax<uint32_t>(index, searchlength, res)
                      : run_supermax<uint64_t>(index, searchlength, res);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
+}
+
+extern "C" int vsa_findtandems(const vsa_index *index, uint64_t searchlength,
+                               vsa_result **result)
+{
+  if (index == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findtandems: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (index->hasindexedqueries)
+  {
+    // Vmengine/ftandem.c:271-275
+    VSA_ERROR("tandem repeat search does not allow query files in index");
+    return -2;
+  }
+  if (searchlength == 0)
+  {
+    VSA_ERROR("tandem repeat search needs a length >= 1");
+    return -2;
+  }
+  if (index->tis_alloc == nullptr || index->suf == nullptr ||
+      index->lcp == nullptr)
+  {
+    VSA_ERROR("tables tis, suf and lcp are required");
+    return -3;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc = (index->isize == 4)
+                     ? run_tandems<uint32_t>(index, searchlength, res)
+                     : run_tandems<uint64_t>(index, searchlength, res);
   if (rc != 0)
   {
     vsa_result_free(res);
