@@ -448,6 +448,15 @@ __device__ __forceinline__ uint64_t vsa_pack8(uint64_t w)
   return x;
 }
 
+// four symbols (the bytes of h, first symbol in the lowest) -> 8 bits in the
+// TOP byte of the result, first symbol most significant; the bytes below are
+// scrap.  One multiplication lines the four 2-bit fields up: byte k moves by
+// 30 - 10k bits, and none of the other partial products reaches bit 24.
+__device__ __forceinline__ uint32_t vsa_pack4top(uint32_t h)
+{
+  return (h & 0x03030303u) * 0x40100401u;
+}
+
 // number of leading key symbols (2 bits each, `nsyms` of them in the low
 // bits of a and b) that agree
 __device__ __forceinline__ uint32_t vsa_keylcp(uint32_t a, uint32_t b,
@@ -509,21 +518,27 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     // 32 query symbols as four 8-byte words (the buffer is padded)
     const vsa_u128 qlo = vsa_load16(query), qhi = vsa_load16(query + 16);
     const uint64_t w0 = qlo.lo, w1 = qlo.hi, w2 = qhi.lo, w3 = qhi.hi;
-    const uint64_t s0 = vsa_specialmask(w0), s1 = vsa_specialmask(w1),
-                   s2 = vsa_specialmask(w2), s3 = vsa_specialmask(w3);
+    // this path exists for the DNA alphabet only (symbols 0..3): every other
+    // byte -- wildcard, separator -- ends the regular prefix
+    const uint64_t notdna = 0xFCFCFCFCFCFCFCFCull;
+    const uint64_t s0 = w0 & notdna, s1 = w1 & notdna, s2 = w2 & notdna,
+                   s3 = w3 & notdna;
     uint32_t valid = 32; // leading regular symbols inside the query
-    if (s0 != 0)
+    if ((s0 | s1 | s2 | s3) != 0)
     {
-      valid = (uint32_t) __builtin_ctzll(s0) >> 3;
-    } else if (s1 != 0)
-    {
-      valid = 8 + ((uint32_t) __builtin_ctzll(s1) >> 3);
-    } else if (s2 != 0)
-    {
-      valid = 16 + ((uint32_t) __builtin_ctzll(s2) >> 3);
-    } else if (s3 != 0)
-    {
-      valid = 24 + ((uint32_t) __builtin_ctzll(s3) >> 3);
+      if (s0 != 0)
+      {
+        valid = (uint32_t) __builtin_ctzll(s0) >> 3;
+      } else if (s1 != 0)
+      {
+        valid = 8 + ((uint32_t) __builtin_ctzll(s1) >> 3);
+      } else if (s2 != 0)
+      {
+        valid = 16 + ((uint32_t) __builtin_ctzll(s2) >> 3);
+      } else
+      {
+        valid = 24 + ((uint32_t) __builtin_ctzll(s3) >> 3);
+      }
     }
     if (valid > querylen)
     {
@@ -537,8 +552,17 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
       state = VSA_LOC_SLOW;
     } else
     {
-      const uint64_t S = (vsa_pack8(w0) << 48) | (vsa_pack8(w1) << 32) |
-                         (vsa_pack8(w2) << 16) | vsa_pack8(w3);
+      const uint32_t shi = (vsa_pack4top((uint32_t) w0) & 0xFF000000u) |
+                           ((vsa_pack4top((uint32_t) (w0 >> 32)) >> 8) &
+                            0x00FF0000u) |
+                           ((vsa_pack4top((uint32_t) w1) >> 16) & 0xFF00u) |
+                           (vsa_pack4top((uint32_t) (w1 >> 32)) >> 24),
+                     slo = (vsa_pack4top((uint32_t) w2) & 0xFF000000u) |
+                           ((vsa_pack4top((uint32_t) (w2 >> 32)) >> 8) &
+                            0x00FF0000u) |
+                           ((vsa_pack4top((uint32_t) w3) >> 16) & 0xFF00u) |
+                           (vsa_pack4top((uint32_t) (w3 >> 32)) >> 24);
+      const uint64_t S = ((uint64_t) shi << 32) | slo;
       const uint64_t code = S >> (64 - 2 * D);
       qkey = (uint32_t) (S >> (64 - 2 * D - 2 * VSA_KEYSYMS)) & VSA_KEYMASK;
       limit = valid - D;
@@ -615,11 +639,14 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   // bucket in the wavefront, so the lanes stay converged
   uint32_t hi = (searching && !small) ? cnt : 0;
   uint32_t maxcnt = hi;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1)
+  if (__ballot(hi != 0) != 0) // rare: skip the six shuffle steps otherwise
   {
-    const uint32_t o = __shfl_xor(maxcnt, d, 64);
-    maxcnt = o > maxcnt ? o : maxcnt;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+      const uint32_t o = __shfl_xor(maxcnt, d, 64);
+      maxcnt = o > maxcnt ? o : maxcnt;
+    }
   }
   for (uint32_t span = maxcnt; span > 0; span >>= 1)
   {
@@ -780,4 +807,23 @@ vsa_wave_reserve(unsigned long long *cursor, uint32_t c)
   }
   base = vsa_shfl64(base, 63);
   return base + incl - c;
+}
+
+// The same for counts of 0 or 1 (the MUM modes: a work-item reports at most
+// one candidate): a ballot and two population counts instead of six shuffle
+// steps.  Must be reached by all 64 lanes.
+__device__ __forceinline__ uint64_t
+vsa_wave_reserve01(unsigned long long *cursor, bool one)
+{
+  const uint64_t mask = __ballot(one);
+  const uint32_t lane = vsa_lane();
+  const uint32_t total = (uint32_t) __popcll(mask),
+                 before = (uint32_t) __popcll(mask & ((1ull << lane) - 1));
+  uint64_t base = 0;
+  if (lane == 0 && total > 0)
+  {
+    base = atomicAdd(cursor, (unsigned long long) total);
+  }
+  base = vsa_shfl64(base, 0);
+  return base + before;
 }
