@@ -85,6 +85,11 @@ def algorithmic_bytes(H, host_index, sample, minlen, w):
 
 def main():
     a = parse()
+    # stdout carries the one JSON line and nothing else: libraries that
+    # print there (RCCL's version banner) go to stderr
+    sys.stdout.flush()
+    jsonfd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +142,15 @@ def main():
             "%.1fs, %d queries/GPU" % (n, info.prefixlength,
                                        info.device_bytes / 1e9, t_index, nq))
 
+    lenbits = 0
+    if distributed:
+        # the pairs of all ranks must be laid out alike: length bits of the
+        # longest query of the job (one number, agreed on once per batch)
+        t = torch.tensor([m], dtype=torch.int64,
+                         device="cpu" if a.rehearse_on_one_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lenbits = max(1, int(t.item()).bit_length())
+
     def sync():
         V.device_synchronize(dev)
         if distributed:
@@ -161,11 +175,12 @@ def main():
         # phase 1: candidates of this rank's queries (no communication), in
         # the order the kernel left them, grouped by the rank that filters
         # their range of the index
-        r = V.findmumcandidates(index, queries, L, ordered=False)
+        # (as pairs of sort key and value, 16 bytes each: half the exchange)
+        r = V.findmumcandidates_packed(index, queries, L, lenbits)
         s = r.stats()
         kernel_ms.append(s.search_kernel_ms)
-        mine = torch.empty(max(r.count, 1) * 4, dtype=torch.int64,
-                           device="cuda")[:r.count * 4]
+        mine = torch.empty(max(r.count, 1) * 2, dtype=torch.int64,
+                           device="cuda")[:r.count * 2]
         send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()))
         r.close()
         cdev = "cuda"
@@ -176,17 +191,17 @@ def main():
         # the uniqueness filter on its range with the carry of the lower ones
         def filter_fn(part, carry):
             part = part.cuda().contiguous()
-            res = V.mumuniqueinquery_range(C.c_void_p(part.data_ptr()),
-                                           part.numel() // 4, carry, dev)
+            res = V.mumuniqueinquery_range_packed(
+                C.c_void_p(part.data_ptr()), part.numel() // 2, lenbits, n,
+                carry, dev)
             st = res.stats()
             res.close()
             return st.count, st.sumlength
 
-        nmum, sumlen, ncand = S.partitioned_mum_filter_presorted(
-            dist, torch, mine, send, top, cdev, filter_fn)
-        # final reduction of the remaining match counters
-        searches, ksearches = S.all_reduce_counters(
-            dist, torch, [s.searches, s.kernel_searches], cdev)
+        nmum, sumlen, ncand, searches, ksearches = \
+            S.partitioned_mum_filter_presorted(
+                dist, torch, mine, send, top, cdev, filter_fn, words=2,
+                extra=[s.searches, s.kernel_searches])
         totals = (nmum, sumlen, searches, ncand, ksearches)
 
     for _ in range(a.warmup):
@@ -315,7 +330,8 @@ def main():
                         "sample": "%d queries, %s" % (rj["queries"],
                                                       rj["source"])}
             out["speedup_vs_cpu_1core"] = qps / (sample.nq / dt)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(jsonfd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -243,6 +243,25 @@ int vsa_findmumcandidates(const vsa_index *index, const vsa_queries *queries,
                           vsa_result **result);
 
 /*
+  The same candidates as PAIRS of 8-byte words, never as 32-byte records:
+    key   = dbstart << lengthbits | (2^lengthbits - 1 - length)
+    value = queryseq << 16 | querystart
+  -- what the filter sorts by, and what it needs to write a record once a
+  candidate has survived.  lengthbits: the same on every rank of a job, at
+  least the bits of the longest query anywhere (at most 16); 0 = the bits of
+  this batch's longest query.  The result is for vsa_result_partition, which
+  then writes rows of the two words (half the bytes of the exchange);
+  vsa_result_fetch / vsa_result_copy_device deliver it as records,
+  vsa_result_device_matches is NULL for it.
+*/
+int vsa_findmumcandidates_packed(const vsa_index *index,
+                                 const vsa_queries *queries,
+                                 uint64_t searchlength, uint32_t lengthbits,
+                                 vsa_result **result);
+/* the lengthbits of a packed result, 0 for a result of records */
+uint32_t vsa_result_packbits(const vsa_result *result);
+
+/*
   The records of a result grouped by the range of the index their dbstart
   falls into -- part p = floor(dbstart * nparts / (totallength + 1)), equal
   dbstarts in the same part -- written to device_matches (room for
@@ -379,6 +398,13 @@ int vsa_mumuniqueinquery(void *device_candidates, uint64_t ncandidates,
 int vsa_mumuniqueinquery_range(void *device_candidates, uint64_t ncandidates,
                                int device, uint64_t carry_dbright,
                                vsa_result **result);
+/* ... on rows of (key, value) pairs as vsa_result_partition wrote them for a
+   packed result; totallength = that of the index.  The MUMs are records. */
+int vsa_mumuniqueinquery_range_packed(const void *device_rows, uint64_t nrows,
+                                      uint32_t lengthbits,
+                                      uint64_t totallength, int device,
+                                      uint64_t carry_dbright,
+                                      vsa_result **result);
 
 /*
   The same three entry points with the reference's delivery model: every

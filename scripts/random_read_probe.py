@@ -1,7 +1,7 @@
 import sys, ctypes as C
 sys.path.insert(0,'.')
 import vstree_amd as V
-for size in (32e9, 3e9):
+for size in (float(a) for a in (sys.argv[1:] or ['32e9', '3e9'])):
     for inf in (1,4,8):
         g=C.c_double()
         V._check(V.lib.vsa_measure_random_read(int(size), inf, 0, C.byref(g)))

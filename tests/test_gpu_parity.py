@@ -780,3 +780,54 @@ def test_tandem_repeats_errors_and_empty_results(V):
     assert V.findtandems(gi, 10 ** 6).count == 0
     with pytest.raises(V.VsaError):
         V.findtandems(gi, 0)
+
+
+def test_packed_candidates_and_filter_in_ranges(V):
+    """the multi-GPU form with 16-byte pairs: vsa_findmumcandidates_packed,
+    vsa_result_partition on it, vsa_mumuniqueinquery_range_packed range by
+    range = the one-piece filter; fetch() of the packed result = the
+    candidate set"""
+    import ctypes as C
+    from vstree_amd import sharding as S
+    idx, q = H.load_case("c1")
+    gi, gq = gpu_index(V, "c1"), gpu_queries(V, q)
+    want = V.findquerymatches(gi, gq, 20, mum=True).fetch()
+    cand = V.findquerymatches(gi, gq, 20, mum=True, cand=True).fetch()
+    for bits in (0, 7, 11):
+        r = V.findmumcandidates_packed(gi, gq, 20, bits)
+        used = r.packbits
+        assert used == (bits or 7) and r.rowwords == 2
+        assert np.array_equal(H.sorted_matches(r.fetch()),
+                              H.sorted_matches(cand))
+        for world in (1, 3):
+            dp = V.device_malloc(max(r.count * 16, 16))
+            counts, top = r.partition(world, idx.n, dp)
+            rows = np.zeros((r.count, 2), np.uint64)
+            V.device_download(rows, dp)
+            assert int(counts.sum()) == r.count
+            assert np.array_equal(
+                H.sorted_matches(S.unpack_candidates(rows, used,
+                                                     V.MATCH_DTYPE)),
+                H.sorted_matches(cand))
+            pieces, carry, off = [], 0, 0
+            for p in range(world):
+                cnt = int(counts[p])
+                part = S.unpack_candidates(rows[off:off + cnt], used,
+                                           V.MATCH_DTYPE)
+                dest = (part["dbstart"] * np.uint64(world)) // np.uint64(
+                    idx.n + 1)
+                assert (dest == p).all()
+                if cnt:
+                    assert int(top[p]) == int(
+                        (part["dbstart"] + part["length"]).max()) - 1
+                res = V.mumuniqueinquery_range_packed(
+                    C.c_void_p(dp.value + 16 * off), cnt, used, idx.n, carry)
+                pieces.append(res.fetch())
+                assert res.stats().sumlength == int(
+                    pieces[-1]["length"].sum())
+                carry = max(carry, int(top[p]))
+                off += cnt
+            V.device_free(dp)
+            assert np.array_equal(np.concatenate(pieces), want)
+    with pytest.raises(V.VsaError):
+        V.findmumcandidates_packed(gi, gq, 20, 5)   # 100 bp need 7 bits

@@ -71,6 +71,24 @@ def _worker(rank, world, port, outdir):
         dist, torch, S.matches_to_tensor(torch, grouped), send, top, "cpu",
         range_filter_fn)
     assert (qn, qs_, qc) == (nmum, sumlen, ncand)
+    # ... and with the candidates as (key, value) pairs of 16 bytes, the rows
+    # vsa_findmumcandidates_packed + vsa_result_partition produce
+    bits = 7
+    rows = S.pack_candidates(grouped, bits)
+    assert np.array_equal(S.unpack_candidates(rows, bits, H.MATCH_DTYPE),
+                          grouped)
+
+    def packed_filter_fn(part, carry):
+        arr = S.unpack_candidates(part.numpy().astype(np.uint64), bits,
+                                  H.MATCH_DTYPE)
+        mums = H.oracle_mumfilter(arr, carry)
+        assert np.array_equal(mums, result["mymums"])
+        return len(mums), int(mums["length"].sum())
+
+    rn, rs, rc_ = S.partitioned_mum_filter_presorted(
+        dist, torch, torch.from_numpy(rows.astype(np.int64).reshape(-1)),
+        send, top, "cpu", packed_filter_fn, words=2)
+    assert (rn, rs, rc_) == (nmum, sumlen, ncand)
     pparts, _ = S.all_gather_matches(
         dist, torch, S.matches_to_tensor(torch, result["mymums"]), "cpu")
     totals = S.all_reduce_counters(dist, torch,

@@ -146,6 +146,10 @@ def _load():
         "vsa_findsupermaximalrepeats": (I, [V, U64, PP]),
         "vsa_findsupermaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findtandems": (I, [V, U64, PP]),
+        "vsa_findmumcandidates_packed": (I, [V, V, U64, C.c_uint32, PP]),
+        "vsa_result_packbits": (C.c_uint32, [V]),
+        "vsa_mumuniqueinquery_range_packed": (
+            I, [V, U64, C.c_uint32, U64, I, U64, PP]),
         "vsa_findtandems_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
         "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
@@ -351,6 +355,16 @@ class Result:
                                         _ptr(counts), _ptr(maxright)))
         return counts, maxright
 
+    @property
+    def packbits(self):
+        """length bits of a packed candidate result, 0 for records"""
+        return int(lib.vsa_result_packbits(self._h))
+
+    @property
+    def rowwords(self):
+        """8-byte words per row that partition() writes"""
+        return 2 if self.packbits else 4
+
     def fetch(self):
         n = self.count
         out = np.zeros(n, MATCH_DTYPE)
@@ -419,6 +433,16 @@ def findmumcandidates(index, queries, searchlength, ordered=True):
     return Result(h)
 
 
+def findmumcandidates_packed(index, queries, searchlength, lengthbits=0):
+    """the candidates as (sort key, value) pairs for the multi-GPU filter,
+    see the header"""
+    h = C.c_void_p()
+    _check(lib.vsa_findmumcandidates_packed(index._h, queries._h,
+                                            int(searchlength),
+                                            int(lengthbits), C.byref(h)))
+    return Result(h)
+
+
 def findmaximalrepeats(index, searchlength):
     """vmatch -l L IDX (Vmengine/vmatfind.c:487), the reference's order."""
     h = C.c_void_p()
@@ -465,6 +489,16 @@ def mumuniqueinquery_range(device_candidates, ncandidates, carry_dbright,
     _check(lib.vsa_mumuniqueinquery_range(device_candidates,
                                           int(ncandidates), device,
                                           int(carry_dbright), C.byref(h)))
+    return Result(h)
+
+
+def mumuniqueinquery_range_packed(device_rows, nrows, lengthbits, totallength,
+                                  carry_dbright, device=0):
+    """the filter on one dbstart range of packed candidate rows"""
+    h = C.c_void_p()
+    _check(lib.vsa_mumuniqueinquery_range_packed(
+        device_rows, int(nrows), int(lengthbits), int(totallength), device,
+        int(carry_dbright), C.byref(h)))
     return Result(h)
 
 

@@ -717,6 +717,23 @@ extern "C" int vsa_result_fetch(const vsa_result *r, vsa_match *matches,
   {
     return -100;
   }
+  if (r->packbits != 0)
+  {
+    // pairs: as records through a temporary
+    void *tmp = nullptr;
+    if (vsa_dev_alloc(&tmp, m * sizeof(vsa_match)) != 0)
+    {
+      return -100;
+    }
+    int rc = vsa_unpack_result(r, m, (vsa_match *) tmp);
+    if (rc == 0 && hipMemcpy(matches, tmp, m * sizeof(vsa_match),
+                             hipMemcpyDeviceToHost) != hipSuccess)
+    {
+      rc = -100;
+    }
+    vsa_dev_free(tmp);
+    return rc;
+  }
   VSA_HIP(hipMemcpy(matches, r->matches, m * sizeof(vsa_match),
                     hipMemcpyDeviceToHost));
   return 0;
@@ -740,6 +757,10 @@ extern "C" int vsa_result_copy_device(const vsa_result *r,
   {
     return -100;
   }
+  if (r->packbits != 0)
+  {
+    return vsa_unpack_result(r, m, (vsa_match *) device_matches);
+  }
   VSA_HIP(hipMemcpy(device_matches, r->matches, m * sizeof(vsa_match),
                     hipMemcpyDeviceToDevice));
   return 0;
@@ -747,7 +768,13 @@ extern "C" int vsa_result_copy_device(const vsa_result *r,
 
 extern "C" const void *vsa_result_device_matches(const vsa_result *r)
 {
-  return r == nullptr ? nullptr : r->matches;
+  // a packed result has no records on the device
+  return (r == nullptr || r->packbits != 0) ? nullptr : r->matches;
+}
+
+extern "C" uint32_t vsa_result_packbits(const vsa_result *r)
+{
+  return r == nullptr ? 0 : r->packbits;
 }
 
 extern "C" void vsa_result_free(vsa_result *r)
@@ -758,6 +785,7 @@ extern "C" void vsa_result_free(vsa_result *r)
   }
   (void) hipSetDevice(r->device);
   vsa_dev_free(r->matches);
+  vsa_dev_free(r->packvals);
   delete r;
 }
 

@@ -317,6 +317,8 @@ vsa_result *newresult(int device)
   r->device = device;
   r->count = 0;
   r->matches = nullptr;
+  r->packbits = 0;
+  r->packvals = nullptr;
   memset(&r->stats, 0, sizeof r->stats);
   return r;
 }
@@ -685,8 +687,9 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
 int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
                      unsigned int lenbits, unsigned int dbbits,
                      hipStream_t stream, DevBuf &mums, uint64_t *nmums,
-                     uint64_t *sumlength)
+                     uint64_t *sumlength, uint64_t carry = 0)
 {
+  // carry: as for mumuniqueinquery
   *nmums = 0;
   *sumlength = 0;
   if (ncand == 0)
@@ -719,7 +722,7 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
   VSA_HIP(hipGetLastError());
   tb = 0;
   VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
-                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  dbright.as<uint64_t>(), carry,
                                   (size_t) ncand, rocprim::maximum<uint64_t>(),
                                   stream));
   if (temp.alloc(tb))
@@ -727,7 +730,7 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     return -100;
   }
   VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
-                                  dbright.as<uint64_t>(), (uint64_t) 0,
+                                  dbright.as<uint64_t>(), carry,
                                   (size_t) ncand, rocprim::maximum<uint64_t>(),
                                   stream));
   k_mum_keyflags<<<nblocks, VSA_BLOCK, 0, stream>>>(
@@ -777,8 +780,10 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
 template <typename IDX>
 int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
               bool domumcand, uint32_t searchlength, vsa_result *res,
-              bool ordered = true)
+              bool ordered = true, uint32_t forcebits = 0)
 {
+  // forcebits != 0 (with domumcand, !ordered): the candidates stay pairs with
+  // this many length bits (vsa_findmumcandidates_packed)
   hipStream_t stream = index->stream;
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
@@ -1053,12 +1058,23 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   double searchms = 0;
   // -mum with the filter: candidates as (sort key, value) pairs, see
   // mumfilter_packed
-  const unsigned int lenbits = bitsfor(queries->maxlength),
+  const bool keeppairs = domum && domumcand && !ordered && forcebits != 0;
+  const unsigned int lenbits =
+                         keeppairs ? forcebits : bitsfor(queries->maxlength),
                      dbbits = bitsfor(index->n);
-  const bool packed = domum && !domumcand && (index->tune & 16u) == 0 &&
+  const bool packed = domum && (!domumcand || keeppairs) &&
+                      ((index->tune & 16u) == 0 || keeppairs) &&
                       lenbits + dbbits <= 64 &&
+                      lenbits >= bitsfor(queries->maxlength) &&
                       queries->maxlength < 0xFFFFu &&
                       ((queries->nq + qs.seqoffset) >> 48) == 0;
+  if (keeppairs && !packed)
+  {
+    VSA_ERROR("packed candidates: %u length bits do not fit this batch "
+              "(longest query %lu, index %lu)", forcebits,
+              (unsigned long) queries->maxlength, (unsigned long) index->n);
+    return -2;
+  }
   const uint32_t packbits = packed ? lenbits : 0;
   const size_t recsize = packed ? 8 : sizeof(vsa_match);
   for (int attempt = 0; attempt < 2; attempt++)
@@ -1192,7 +1208,16 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     needed += nfirst;
   }
   res->stats.candidates = domum ? needed : 0;
-  if (domum && !domumcand)
+  if (keeppairs)
+  {
+    res->count = needed;
+    res->packbits = lenbits;
+    if (needed > 0)
+    {
+      res->matches = (vsa_match *) keys.release();
+      res->packvals = (uint64_t *) out.release();
+    }
+  } else if (domum && !domumcand)
   {
     DevBuf mums;
     uint64_t nm = 0;
@@ -1244,6 +1269,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   if (mumsum != ~0ull)
   {
     res->stats.sumlength = mumsum; // the filter summed the lengths already
+    return 0;
+  }
+  if (keeppairs)
+  {
+    res->stats.sumlength = 0; // of candidates: nobody asks
     return 0;
   }
   return sumlengths(res->matches, res->count, stream, &res->stats.sumlength);
@@ -1660,6 +1690,61 @@ extern "C" int vsa_findmumcandidates(const vsa_index *index,
   return 0;
 }
 
+extern "C" int vsa_findmumcandidates_packed(const vsa_index *index,
+                                            const vsa_queries *queries,
+                                            uint64_t searchlength,
+                                            uint32_t lengthbits,
+                                            vsa_result **result)
+{
+  if (index == nullptr || queries == nullptr || result == nullptr)
+  {
+    VSA_ERROR("vsa_findmumcandidates_packed: NULL argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (index->bck == nullptr)
+  {
+    VSA_ERROR("table bck is not loaded");
+    return -3;
+  }
+  if (searchlength < index->pl || searchlength > 0xFFFFFFF0ull)
+  {
+    // Vmengine/fquery.c:440-446
+    VSA_ERROR("searchlength=%lu must be >= %lu=prefixlen",
+              (unsigned long) searchlength, (unsigned long) index->pl);
+    return -2;
+  }
+  if (lengthbits == 0)
+  {
+    lengthbits = bitsfor(queries->maxlength);
+  }
+  if (lengthbits > 16)
+  {
+    VSA_ERROR("packed candidates: at most 16 length bits");
+    return -2;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(index->device);
+  const int rc =
+      (index->isize == 4)
+          ? run_query<uint32_t>(index, queries, true, true,
+                                (uint32_t) searchlength, res, false,
+                                lengthbits)
+          : run_query<uint64_t>(index, queries, true, true,
+                                (uint32_t) searchlength, res, false,
+                                lengthbits);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  return 0;
+}
+
 // records of a result by the range of the index their dbstart falls into:
 // part p = floor(dbstart * nparts / (totallength + 1)).  A counting sort in
 // two passes over the records (the order inside a part is free): per
@@ -1670,8 +1755,31 @@ extern "C" int vsa_findmumcandidates(const vsa_index *index,
 // wavefront, which is slower than the whole rest (measured).
 #define VSA_PART_MAX 256
 
+// PACKBITS view of the input: records (m) or pairs (key[], val[])
+struct PartInput
+{
+  const vsa_match *m;
+  const uint64_t *key, *val;
+  uint32_t packbits;
+};
+
+__device__ __forceinline__ void part_read(const PartInput &in, uint64_t t,
+                                          uint64_t &dbstart, uint64_t &length)
+{
+  if (in.packbits != 0)
+  {
+    const uint64_t k = in.key[t], mask = (1ull << in.packbits) - 1;
+    dbstart = k >> in.packbits;
+    length = mask - (k & mask);
+  } else
+  {
+    dbstart = in.m[t].dbstart;
+    length = in.m[t].length;
+  }
+}
+
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_partition_count(const vsa_match *__restrict__ m, uint64_t n,
+k_partition_count(const PartInput in, uint64_t n,
                   uint32_t nparts, uint64_t totallength, uint64_t nblocks,
                   uint32_t *__restrict__ blockhist,
                   unsigned long long *__restrict__ blocktop)
@@ -1687,12 +1795,12 @@ k_partition_count(const vsa_match *__restrict__ m, uint64_t n,
   __syncthreads();
   if (t < n)
   {
-    const uint32_t p =
-        (uint32_t) ((m[t].dbstart * nparts) / (totallength + 1));
+    uint64_t dbstart, length;
+    part_read(in, t, dbstart, length);
+    const uint32_t p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
     atomicAdd(&hist[p], 1u);
     // right end of the match in the index (cleanMUMcand.c: dbright)
-    atomicMax(&top[p],
-              (unsigned long long) (m[t].dbstart + m[t].length - 1));
+    atomicMax(&top[p], (unsigned long long) (dbstart + length - 1));
   }
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
@@ -1740,10 +1848,10 @@ k_partition_summary(const uint64_t *__restrict__ offsets,
 }
 
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_partition_place(const vsa_match *__restrict__ m, uint64_t n,
+k_partition_place(const PartInput in, uint64_t n,
                   uint32_t nparts, uint64_t totallength, uint64_t nblocks,
                   const uint64_t *__restrict__ offsets,
-                  vsa_match *__restrict__ out)
+                  void *__restrict__ out)
 {
   __shared__ unsigned int taken[VSA_PART_MAX];
   const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
@@ -1752,15 +1860,30 @@ k_partition_place(const vsa_match *__restrict__ m, uint64_t n,
     taken[p] = 0;
   }
   __syncthreads();
-  if (t < n)
+  if (t < n && in.packbits != 0)
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(m + t);
+    // rows of two words: key, value
+    const uint64_t k = in.key[t], v = in.val[t];
+    const uint32_t p =
+        (uint32_t) (((k >> in.packbits) * nparts) / (totallength + 1));
+    const uint64_t slot = offsets[(uint64_t) p * nblocks + blockIdx.x] +
+                          atomicAdd(&taken[p], 1u);
+    uint4 row;
+    row.x = (uint32_t) k;
+    row.y = (uint32_t) (k >> 32);
+    row.z = (uint32_t) v;
+    row.w = (uint32_t) (v >> 32);
+    reinterpret_cast<uint4 *>(out)[slot] = row;
+  } else if (t < n)
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(in.m + t);
     const uint4 lo = src[0], hi = src[1];
     const uint64_t dbstart = ((uint64_t) lo.w << 32) | lo.z;
     const uint32_t p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
     const uint64_t slot = offsets[(uint64_t) p * nblocks + blockIdx.x] +
                           atomicAdd(&taken[p], 1u);
-    uint4 *dst = reinterpret_cast<uint4 *>(out + slot);
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<vsa_match *>(out) +
+                                           slot);
     dst[0] = lo;
     dst[1] = hi;
   }
@@ -1806,9 +1929,14 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   {
     return -100;
   }
+  PartInput in;
+  in.m = result->matches;
+  in.key = reinterpret_cast<const uint64_t *>(result->matches);
+  in.val = result->packvals;
+  in.packbits = result->packbits;
   VSA_HIP(hipMemsetAsync(hist.as<uint32_t>() + cells, 0, 4, stream));
   k_partition_count<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
-      result->matches, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
+      in, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
       top.as<unsigned long long>());
   VSA_HIP(hipGetLastError());
   auto widen = rocprim::make_transform_iterator(hist.as<uint32_t>(),
@@ -1829,8 +1957,8 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
       summary.as<unsigned long long>() + VSA_PART_MAX + 1);
   VSA_HIP(hipGetLastError());
   k_partition_place<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
-      result->matches, n, nparts, totallength, nblocks,
-      offsets.as<uint64_t>(), (vsa_match *) device_matches);
+      in, n, nparts, totallength, nblocks, offsets.as<uint64_t>(),
+      device_matches);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipMemcpyAsync(host, summary.p, (2 * VSA_PART_MAX + 1) * 8,
                          hipMemcpyDeviceToHost, stream));
@@ -2020,6 +2148,110 @@ extern "C" int vsa_mumuniqueinquery_range(void *device_candidates,
 {
   return mumfilter_entry(device_candidates, ncandidates, device,
                          carry_dbright, result);
+}
+
+// rows of (key, value) -> two arrays
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_split_rows(const uint4 *__restrict__ rows, uint64_t n,
+             uint64_t *__restrict__ key, uint64_t *__restrict__ val)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t < n)
+  {
+    const uint4 r = rows[t];
+    key[t] = ((uint64_t) r.y << 32) | r.x;
+    val[t] = ((uint64_t) r.w << 32) | r.z;
+  }
+}
+
+// pairs -> records, in place order (vsa_result_fetch of a packed result)
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_unpack_pairs(const uint64_t *__restrict__ key,
+               const uint64_t *__restrict__ val, uint64_t n,
+               uint32_t packbits, vsa_match *__restrict__ out)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t < n)
+  {
+    const uint64_t k = key[t], v = val[t], mask = (1ull << packbits) - 1;
+    vsa_match m;
+    m.length = mask - (k & mask);
+    m.dbstart = k >> packbits;
+    m.queryseq = v >> 16;
+    m.querystart = v & 0xFFFFu;
+    out[t] = m;
+  }
+}
+
+int vsa_unpack_result(const vsa_result *r, uint64_t count, vsa_match *device)
+{
+  k_unpack_pairs<<<gridfor(count), VSA_BLOCK>>>(
+      reinterpret_cast<const uint64_t *>(r->matches), r->packvals, count,
+      r->packbits, device);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
+                                                 uint64_t nrows,
+                                                 uint32_t lengthbits,
+                                                 uint64_t totallength,
+                                                 int device,
+                                                 uint64_t carry_dbright,
+                                                 vsa_result **result)
+{
+  if (result == nullptr || (device_rows == nullptr && nrows > 0) ||
+      lengthbits == 0 || lengthbits > 16 ||
+      lengthbits + bitsfor(totallength) > 64)
+  {
+    VSA_ERROR("vsa_mumuniqueinquery_range_packed: bad argument");
+    return -1;
+  }
+  *result = nullptr;
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  vsa_result *res = newresult(device);
+  hipStream_t stream = nullptr; // default stream: no index handle here
+  Timer tall(stream);
+  DevBuf keys, vals, mums;
+  uint64_t nm = 0, sum = 0;
+  tall.start();
+  int rc = 0;
+  if (nrows > 0)
+  {
+    if (keys.alloc(nrows * 8) || vals.alloc(nrows * 8))
+    {
+      rc = -100;
+    } else
+    {
+      k_split_rows<<<gridfor(nrows), VSA_BLOCK, 0, stream>>>(
+          reinterpret_cast<const uint4 *>(device_rows), nrows,
+          keys.as<uint64_t>(), vals.as<uint64_t>());
+      rc = hipGetLastError() == hipSuccess
+               ? mumfilter_packed(keys, vals, nrows, lengthbits,
+                                  bitsfor(totallength), stream, mums, &nm,
+                                  &sum, carry_dbright)
+               : -100;
+    }
+  }
+  tall.stop();
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  (void) hipStreamSynchronize(stream);
+  res->count = nm;
+  res->matches = (vsa_match *) mums.release();
+  res->stats.count = nm;
+  res->stats.candidates = nrows;
+  res->stats.sumlength = sum;
+  res->stats.total_device_ms = tall.ms();
+  *result = res;
+  return 0;
 }
 
 extern "C" int vsa_findmaximalrepeats(const vsa_index *index,

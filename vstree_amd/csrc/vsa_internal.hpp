@@ -143,7 +143,16 @@ struct vsa_result
   uint64_t count;
   vsa_match *matches; // device
   vsa_stats stats;
+  // packbits != 0: MUM candidates as pairs instead of records (multi-GPU
+  // -mum, vsa_findmumcandidates_packed): `matches` holds count sort keys
+  // dbstart << packbits | (2^packbits - 1 - length), packvals the values
+  // queryseq << 16 | querystart that go with them
+  uint32_t packbits;
+  uint64_t *packvals;
 };
+
+// pairs of a packed result as records on the device (esa_search.hip)
+int vsa_unpack_result(const vsa_result *r, uint64_t count, vsa_match *device);
 
 // device-side view of a query batch
 struct DevQueries

@@ -31,23 +31,23 @@ def all_reduce_counters(dist, torch, values, device):
     return [int(x) for x in t.tolist()]
 
 
-def all_gather_matches(dist, torch, local, device):
-    """local: int64 tensor [count*4] of this rank's vsa_match records (on
-    `device`).  Returns (list of per-rank tensors trimmed to their counts,
-    counts).  Ragged lists are padded to the longest one for the collective."""
+def all_gather_matches(dist, torch, local, device, words=MATCH_WORDS):
+    """local: int64 tensor [count*words] of this rank's rows (vsa_match
+    records: 4 words; packed candidates: 2) on `device`.  Returns (list of
+    per-rank tensors trimmed to their counts, counts).  Ragged lists are
+    padded to the longest one for the collective."""
     world = dist.get_world_size()
-    count = torch.tensor([local.numel() // MATCH_WORDS], dtype=torch.int64,
+    count = torch.tensor([local.numel() // words], dtype=torch.int64,
                          device=device)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)
     counts = [int(c.item()) for c in counts]
-    cap = max(counts) * MATCH_WORDS
-    padded = torch.zeros(max(cap, MATCH_WORDS), dtype=torch.int64,
-                         device=device)
+    cap = max(counts) * words
+    padded = torch.zeros(max(cap, words), dtype=torch.int64, device=device)
     padded[:local.numel()] = local
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded)
-    return [g[:c * MATCH_WORDS] for g, c in zip(gathered, counts)], counts
+    return [g[:c * words] for g, c in zip(gathered, counts)], counts
 
 
 def global_mum_filter(dist, torch, local_candidates, device, filter_fn):
@@ -94,15 +94,19 @@ def _exchange_rows(dist, torch, rows, dest, device):
 
 
 def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
-                                     device, filter_fn):
+                                     device, filter_fn, words=MATCH_WORDS,
+                                     extra=()):
     """partitioned_mum_filter for candidates that vsa_result_partition has
     grouped by destination already (send[r] rows for rank r, maxright[r] =
     their largest right end): no sorting on this side and three collectives --
     one all-gather of the 2*world numbers of every rank (split sizes of the
     exchange and the carries), the all-to-all of the rows, the all-reduce of
-    the counters."""
+    the counters.  words = 8-byte words per row: 4 for records, 2 for the
+    (key, value) pairs of vsa_findmumcandidates_packed.  extra: more local
+    counters to sum over the ranks in the same all-reduce; their totals
+    follow the three results."""
     world, me = dist.get_world_size(), dist.get_rank()
-    rows = rows.reshape(-1, MATCH_WORDS)
+    rows = rows.reshape(-1, words)
     meta = torch.as_tensor(np.concatenate([np.asarray(send, np.int64),
                                            np.asarray(maxright, np.int64)]),
                            device=device)
@@ -113,24 +117,24 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     recv = [int(x) for x in sends[:, me]]
     # largest right end among ALL candidates of the ranges below mine
     carry = int(tops[:, :me].max()) if me > 0 else 0
-    mine = torch.empty((sum(recv), MATCH_WORDS), dtype=torch.int64,
-                       device=device)
+    mine = torch.empty((sum(recv), words), dtype=torch.int64, device=device)
     try:
         dist.all_to_all_single(mine, rows, recv,
                                [int(x) for x in sends[me]])
     except (RuntimeError, NotImplementedError):
         # backend without all-to-all (gloo in the CPU tests): gather all,
         # cut out what is addressed to this rank
-        parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device)
+        parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device,
+                                      words)
         keep = []
         for r, p in enumerate(parts):
             off = int(sends[r, :me].sum())
-            keep.append(p.reshape(-1, MATCH_WORDS)[off:off + recv[r]])
+            keep.append(p.reshape(-1, words)[off:off + recv[r]])
         mine = torch.cat(keep) if keep else rows[:0]
     nmum, sumlen = filter_fn(mine.reshape(-1), carry)
-    nmum, sumlen, ncand = all_reduce_counters(
-        dist, torch, [nmum, sumlen, rows.shape[0]], device)
-    return nmum, sumlen, ncand
+    totals = all_reduce_counters(
+        dist, torch, [nmum, sumlen, rows.shape[0]] + list(extra), device)
+    return tuple(totals) if extra else tuple(totals[:3])
 
 
 def partitioned_mum_filter(dist, torch, local_candidates, totallength,
@@ -171,4 +175,27 @@ def tensor_to_matches(tensor, dtype):
     out = np.zeros(a.shape[0], dtype)
     for i, name in enumerate(dtype.names):
         out[name] = a[:, i]
+    return out
+
+
+def pack_candidates(matches, lengthbits):
+    """host restatement of the pair layout of vsa_findmumcandidates_packed:
+    structured match array -> uint64 array [n, 2] of (key, value) rows"""
+    mask = np.uint64((1 << lengthbits) - 1)
+    rows = np.zeros((len(matches), 2), np.uint64)
+    rows[:, 0] = (matches["dbstart"] << np.uint64(lengthbits)) | (
+        mask - matches["length"])
+    rows[:, 1] = (matches["queryseq"] << np.uint64(16)) | matches["querystart"]
+    return rows
+
+
+def unpack_candidates(rows, lengthbits, dtype):
+    """(key, value) rows -> structured match array"""
+    rows = np.asarray(rows, np.uint64).reshape(-1, 2)
+    mask = np.uint64((1 << lengthbits) - 1)
+    out = np.zeros(rows.shape[0], dtype)
+    out["length"] = mask - (rows[:, 0] & mask)
+    out["dbstart"] = rows[:, 0] >> np.uint64(lengthbits)
+    out["queryseq"] = rows[:, 1] >> np.uint64(16)
+    out["querystart"] = rows[:, 1] & np.uint64(0xFFFF)
     return out
