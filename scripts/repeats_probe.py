@@ -29,13 +29,15 @@ print("index %d bp (copy of %d bp, one substitution per %d) built in %.1fs"
 for name, fn in (("maximal repeats", V.findmaximalrepeats),
                  ("supermaximal repeats", V.findsupermaximalrepeats)):
     for rep in range(3):
+        tw = time.time()
         r = fn(idx, L)
+        tw = time.time() - tw
         s = r.stats()
-        print("%s -l %d: %d matches, %d candidates, total %.2f ms "
-              "(%.1f M matches/s)" % (name, L, s.count, s.candidates,
-                                      s.total_device_ms,
-                                      s.count / s.total_device_ms / 1e3),
-              flush=True)
+        print("%s -l %d: %d matches, %d candidates, total %.2f ms (call "
+              "%.2f ms; %.1f M matches/s)" % (name, L, s.count, s.candidates,
+                                              s.total_device_ms, tw * 1e3,
+                                              s.count / s.total_device_ms
+                                              / 1e3), flush=True)
         if rep == 0 and len(tis) <= 3000000:
             import helpers as H
             t = idx.download()

@@ -34,12 +34,14 @@ idx = V.Index.build(tis, 4, 0)
 print("index %d bp with %d tandem arrays built in %.1fs"
       % (len(tis), narrays, time.time() - t0), flush=True)
 for rep in range(3):
+    tw = time.time()
     r = V.findtandems(idx, L)
+    tw = time.time() - tw
     s = r.stats()
     print("tandem repeats -l %d: %d repeats, %d positions with lcp >= L, "
-          "interval kernel %.2f ms, total %.2f ms"
-          % (L, s.count, s.candidates, s.search_kernel_ms, s.total_device_ms),
-          flush=True)
+          "interval kernel %.2f ms, total %.2f ms (call %.2f ms)"
+          % (L, s.count, s.candidates, s.search_kernel_ms, s.total_device_ms,
+             tw * 1e3), flush=True)
     if rep == 0 and len(tis) <= 3000000:
         import helpers as H
         t = idx.download()

@@ -11,8 +11,12 @@
 namespace
 {
 
-const size_t kMaxCachedBlock = 2ull << 30;  // do not keep blocks above 2 GiB
-const size_t kMaxCachedTotal = 12ull << 30; // per process
+// 288 GB of HBM, 114 GB of it the 3 Gbp index: keeping the temporaries of
+// the largest batches costs nothing; giving them back costs a device
+// synchronisation per block (vsa_dev_alloc trims the cache and retries when
+// an allocation fails)
+const size_t kMaxCachedBlock = 8ull << 30;  // do not keep blocks above 8 GiB
+const size_t kMaxCachedTotal = 48ull << 30; // per process
 
 struct Block
 {
