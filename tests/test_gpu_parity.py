@@ -831,3 +831,37 @@ def test_packed_candidates_and_filter_in_ranges(V):
             assert np.array_equal(np.concatenate(pieces), want)
     with pytest.raises(V.VsaError):
         V.findmumcandidates_packed(gi, gq, 20, 5)   # 100 bp need 7 bits
+
+
+def test_mum_filter_runs_of_equal_dbstart(V):
+    """the filter sorts by dbstart alone and settles runs of equal dbstarts
+    by looking at the run (k_mum_keyflags_runs); beyond 64 members it sorts on
+    all bits instead.  Reads of different lengths from the same start: short
+    runs with a unique longest member, with the longest twice, and a run of
+    101 -- all against the oracle."""
+    rng = np.random.default_rng(8)
+    n = 50000
+    tis = rng.integers(0, 4, n).astype(np.uint8)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(n, gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+
+    def read(p, length):
+        # ends in a foreign symbol so that the match stops at `length`
+        r = np.concatenate([tis[p:p + length],
+                            [(int(tis[p + length]) + 1) % 4]])
+        return r.astype(np.uint8)
+
+    for runs in ([(1000, [30, 40, 50, 35]), (3000, [60, 60, 45]),
+                  (7000, [25]), (7001, [80, 70, 80, 30]),
+                  (9000, list(range(30, 40)))],
+                 [(2000, list(range(30, 131))), (5000, [50, 40])],
+                 [(2000, [90] * 70 + [95]), (2100, [90] * 70 + [95, 95])]):
+        reads = [read(p, m) for p, ms in runs for m in ms]
+        reads += [tis[p:p + 70] for p in rng.integers(0, n - 200, 300)]
+        order = rng.permutation(len(reads))
+        q = H.Queries.from_list([reads[i] for i in order])
+        got = V.findquerymatches(gi, gpu_queries(V, q), 20, mum=True).fetch()
+        want = H.oracle_querymatches(host, q, 20, mum=True, speedup=0)
+        assert np.array_equal(got, want), runs[0]

@@ -700,77 +700,100 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
   const size_t nblocks = gridfor(ncand);
   if (k2.alloc(ncand * 8) || v2.alloc(ncand * 8) || ends.alloc(ncand * 8) ||
       dbright.alloc(ncand * 8) || keep.alloc(ncand) ||
-      slots.alloc(ncand * 4) || dcount.alloc(16) ||
+      slots.alloc(ncand * 4) || dcount.alloc(24) ||
       blocksum.alloc(nblocks * 8) || mums.alloc(ncand * sizeof(vsa_match)))
   {
     return -100;
   }
+  // Sorted by dbstart alone where the runs of equal dbstarts are short (see
+  // k_mum_keyflags_runs; decided afterwards from a flag that comes back with
+  // the counts), by (dbstart, length down) otherwise.
   size_t tb = 0;
-  VSA_HIP(rocprim::radix_sort_pairs(
-      nullptr, tb, keys.as<uint64_t>(), k2.as<uint64_t>(),
-      vals.as<uint64_t>(), v2.as<uint64_t>(), (size_t) ncand, 0u,
-      lenbits + dbbits, stream));
-  if (temp.alloc(tb))
+  uint64_t got[3] = {0, 0, 0};
+  for (int pass = 0; pass < 2; pass++)
   {
-    return -100;
-  }
-  VSA_HIP(rocprim::radix_sort_pairs(
-      temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<uint64_t>(),
-      v2.as<uint64_t>(), (size_t) ncand, 0u, lenbits + dbbits, stream));
-  k_mum_keyends<<<nblocks, VSA_BLOCK, 0, stream>>>(
-      k2.as<uint64_t>(), ncand, lenbits, ends.as<uint64_t>());
-  VSA_HIP(hipGetLastError());
-  tb = 0;
-  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
-                                  dbright.as<uint64_t>(), carry,
-                                  (size_t) ncand, rocprim::maximum<uint64_t>(),
-                                  stream));
-  if (temp.alloc(tb))
-  {
-    return -100;
-  }
-  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
-                                  dbright.as<uint64_t>(), carry,
-                                  (size_t) ncand, rocprim::maximum<uint64_t>(),
-                                  stream));
-  k_mum_keyflags<<<nblocks, VSA_BLOCK, 0, stream>>>(
-      k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
-      lenbits, keep.as<uint8_t>());
-  VSA_HIP(hipGetLastError());
-  auto keepit =
-      rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
-  tb = 0;
-  VSA_HIP(rocprim::exclusive_scan(nullptr, tb, keepit, slots.as<uint32_t>(),
-                                  (uint32_t) 0, (size_t) ncand,
-                                  rocprim::plus<uint32_t>(), stream));
-  if (temp.alloc(tb))
-  {
-    return -100;
-  }
-  VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
-                                  (uint32_t) 0, (size_t) ncand,
-                                  rocprim::plus<uint32_t>(), stream));
-  k_mum_writepacked<<<nblocks, VSA_BLOCK, 0, stream>>>(
-      k2.as<uint64_t>(), v2.as<uint64_t>(), keep.as<uint8_t>(),
-      slots.as<uint32_t>(), ncand, lenbits, mums.as<vsa_match>(),
-      dcount.as<uint64_t>(), blocksum.as<unsigned long long>());
-  VSA_HIP(hipGetLastError());
-  tb = 0;
-  VSA_HIP(rocprim::reduce(nullptr, tb, blocksum.as<unsigned long long>(),
-                          dcount.as<unsigned long long>() + 1, 0ull, nblocks,
-                          rocprim::plus<unsigned long long>(), stream));
-  if (temp.alloc(tb))
-  {
-    return -100;
-  }
-  VSA_HIP(rocprim::reduce(temp.p, tb, blocksum.as<unsigned long long>(),
-                          dcount.as<unsigned long long>() + 1, 0ull, nblocks,
-                          rocprim::plus<unsigned long long>(), stream));
-  const Fetch f[2] = {{dcount.p, 8}, {dcount.as<uint64_t>() + 1, 8}};
-  uint64_t got[2];
-  if (fetchwords(stream, f, 2, got))
-  {
-    return -100;
+    const bool byruns = pass == 0;
+    const unsigned int firstbit = byruns ? lenbits : 0u;
+    VSA_HIP(hipMemsetAsync(dcount.p, 0, 24, stream));
+    tb = 0;
+    VSA_HIP(rocprim::radix_sort_pairs(
+        nullptr, tb, keys.as<uint64_t>(), k2.as<uint64_t>(),
+        vals.as<uint64_t>(), v2.as<uint64_t>(), (size_t) ncand, firstbit,
+        lenbits + dbbits, stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::radix_sort_pairs(
+        temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<uint64_t>(),
+        v2.as<uint64_t>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
+    k_mum_keyends<<<nblocks, VSA_BLOCK, 0, stream>>>(
+        k2.as<uint64_t>(), ncand, lenbits, ends.as<uint64_t>());
+    VSA_HIP(hipGetLastError());
+    tb = 0;
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
+                                    dbright.as<uint64_t>(), carry,
+                                    (size_t) ncand, rocprim::maximum<uint64_t>(),
+                                    stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
+                                    dbright.as<uint64_t>(), carry,
+                                    (size_t) ncand, rocprim::maximum<uint64_t>(),
+                                    stream));
+    if (byruns)
+    {
+      k_mum_keyflags_runs<<<nblocks, VSA_BLOCK, 0, stream>>>(
+          k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
+          lenbits, keep.as<uint8_t>(), dcount.as<unsigned int>() + 4);
+    } else
+    {
+      k_mum_keyflags<<<nblocks, VSA_BLOCK, 0, stream>>>(
+          k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
+          lenbits, keep.as<uint8_t>());
+    }
+    VSA_HIP(hipGetLastError());
+    auto keepit =
+        rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
+    tb = 0;
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, keepit, slots.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) ncand,
+                                    rocprim::plus<uint32_t>(), stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
+                                    (uint32_t) 0, (size_t) ncand,
+                                    rocprim::plus<uint32_t>(), stream));
+    k_mum_writepacked<<<nblocks, VSA_BLOCK, 0, stream>>>(
+        k2.as<uint64_t>(), v2.as<uint64_t>(), keep.as<uint8_t>(),
+        slots.as<uint32_t>(), ncand, lenbits, mums.as<vsa_match>(),
+        dcount.as<uint64_t>(), blocksum.as<unsigned long long>());
+    VSA_HIP(hipGetLastError());
+    tb = 0;
+    VSA_HIP(rocprim::reduce(nullptr, tb, blocksum.as<unsigned long long>(),
+                            dcount.as<unsigned long long>() + 1, 0ull, nblocks,
+                            rocprim::plus<unsigned long long>(), stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::reduce(temp.p, tb, blocksum.as<unsigned long long>(),
+                            dcount.as<unsigned long long>() + 1, 0ull, nblocks,
+                            rocprim::plus<unsigned long long>(), stream));
+    const Fetch f[3] = {{dcount.p, 8}, {dcount.as<uint64_t>() + 1, 8},
+                        {dcount.as<uint64_t>() + 2, 8}};
+    if (fetchwords(stream, f, 3, got))
+    {
+      return -100;
+    }
+    if (!byruns || got[2] == 0)
+    {
+      break;
+    }
   }
   *nmums = got[0];
   *sumlength = got[1];
