@@ -579,11 +579,11 @@ def test_wide_device_tables(V, case, monkeypatch):
             assert np.array_equal(got, want), (case, key)
 
 
-@pytest.mark.parametrize("tune", [2, 4, 8, 16])
+@pytest.mark.parametrize("tune", [2, 4, 8, 16, 32])
 def test_older_work_reduction_paths_still_agree(V, tune, monkeypatch):
     """VSA_TUNE bits 1-3 switch the first pass / the plan / all work
-    reduction off, bit 4 the packed candidate pairs of the MUM filter
-    (esa_search.hip): the lists must not change"""
+    reduction off, bit 4 the packed candidate pairs of the MUM filter, bit 5
+    their 4-byte values (esa_search.hip): the lists must not change"""
     monkeypatch.setenv("VSA_TUNE", str(tune))
     idx, q = H.load_case("c1")
     i = idx.as_width(64)

@@ -684,11 +684,14 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
 // querystart (k_query_search with packbits).  One sort of the pairs, the
 // filter on the keys, and the surviving pairs become the records: the
 // candidates never exist as 32-byte records.
+template <typename VAL = uint64_t>
 int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
                      unsigned int lenbits, unsigned int dbbits,
                      hipStream_t stream, DevBuf &mums, uint64_t *nmums,
-                     uint64_t *sumlength, uint64_t carry = 0)
+                     uint64_t *sumlength, uint64_t carry = 0,
+                     unsigned int valbits = 0, uint64_t seqoffset = 0)
 {
+  // VAL, valbits, seqoffset: see k_mum_writepacked
   // carry: as for mumuniqueinquery
   *nmums = 0;
   *sumlength = 0;
@@ -698,9 +701,9 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
   }
   DevBuf k2, v2, ends, dbright, keep, slots, temp, dcount, blocksum;
   const size_t nblocks = gridfor(ncand);
-  if (k2.alloc(ncand * 8) || v2.alloc(ncand * 8) || ends.alloc(ncand * 8) ||
-      dbright.alloc(ncand * 8) || keep.alloc(ncand) ||
-      slots.alloc(ncand * 4) || dcount.alloc(24) ||
+  if (k2.alloc(ncand * 8) || v2.alloc(ncand * sizeof(VAL)) ||
+      ends.alloc(ncand * 8) || dbright.alloc(ncand * 8) ||
+      keep.alloc(ncand) || slots.alloc(ncand * 4) || dcount.alloc(24) ||
       blocksum.alloc(nblocks * 8) || mums.alloc(ncand * sizeof(vsa_match)))
   {
     return -100;
@@ -717,16 +720,15 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     VSA_HIP(hipMemsetAsync(dcount.p, 0, 24, stream));
     tb = 0;
     VSA_HIP(rocprim::radix_sort_pairs(
-        nullptr, tb, keys.as<uint64_t>(), k2.as<uint64_t>(),
-        vals.as<uint64_t>(), v2.as<uint64_t>(), (size_t) ncand, firstbit,
-        lenbits + dbbits, stream));
+        nullptr, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<VAL>(),
+        v2.as<VAL>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
     if (temp.alloc(tb))
     {
       return -100;
     }
     VSA_HIP(rocprim::radix_sort_pairs(
-        temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<uint64_t>(),
-        v2.as<uint64_t>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
+        temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<VAL>(),
+        v2.as<VAL>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
     k_mum_keyends<<<nblocks, VSA_BLOCK, 0, stream>>>(
         k2.as<uint64_t>(), ncand, lenbits, ends.as<uint64_t>());
     VSA_HIP(hipGetLastError());
@@ -768,10 +770,11 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
                                     (uint32_t) 0, (size_t) ncand,
                                     rocprim::plus<uint32_t>(), stream));
-    k_mum_writepacked<<<nblocks, VSA_BLOCK, 0, stream>>>(
-        k2.as<uint64_t>(), v2.as<uint64_t>(), keep.as<uint8_t>(),
-        slots.as<uint32_t>(), ncand, lenbits, mums.as<vsa_match>(),
-        dcount.as<uint64_t>(), blocksum.as<unsigned long long>());
+    k_mum_writepacked<VAL><<<nblocks, VSA_BLOCK, 0, stream>>>(
+        k2.as<uint64_t>(), v2.as<VAL>(), keep.as<uint8_t>(),
+        slots.as<uint32_t>(), ncand, lenbits, valbits, seqoffset,
+        mums.as<vsa_match>(), dcount.as<uint64_t>(),
+        blocksum.as<unsigned long long>());
     VSA_HIP(hipGetLastError());
     tb = 0;
     VSA_HIP(rocprim::reduce(nullptr, tb, blocksum.as<unsigned long long>(),
@@ -1099,7 +1102,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     return -2;
   }
   const uint32_t packbits = packed ? lenbits : 0;
-  const size_t recsize = packed ? 8 : sizeof(vsa_match);
+  // 4-byte values where query number and offset fit (not for pairs that
+  // travel to other ranks: those carry the global query number)
+  const uint32_t valbits =
+      (packed && !keeppairs && (index->tune & 32u) == 0 &&
+       ((queries->nq << lenbits) >> 32) == 0)
+          ? lenbits
+          : 0;
+  const size_t recsize = valbits != 0 ? 4 : (packed ? 8 : sizeof(vsa_match));
   for (int attempt = 0; attempt < 2; attempt++)
   {
     if (rawout.alloc(nshards * shardcap * recsize) ||
@@ -1115,7 +1125,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       <<<(unsigned int) ((nwork + BLK - 1) / BLK), BLK, 0, stream>>>(         \
           ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
-          nshards - 1, cursor.as<unsigned long long>(), packbits)
+          nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
 #define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
   do                                                                          \
   {                                                                           \
@@ -1204,7 +1214,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     {
       return -100;
     }
-    if (needed > 0 && packed)
+    if (needed > 0 && valbits != 0)
+    {
+      k_compact_shards<uint32_t><<<nshards, VSA_BLOCK, 0, stream>>>(
+          rawout.as<uint32_t>(), rawkeys.as<uint64_t>(), shardcap,
+          cursor.as<unsigned long long>(), doff.as<uint64_t>(),
+          out.as<uint32_t>(), keys.as<uint64_t>());
+      VSA_HIP(hipGetLastError());
+    } else if (needed > 0 && packed)
     {
       k_compact_shards<uint64_t><<<nshards, VSA_BLOCK, 0, stream>>>(
           rawout.as<uint64_t>(), rawkeys.as<uint64_t>(), shardcap,
@@ -1225,7 +1242,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
           wfslot.as<uint32_t>(), queries->nq, perquery, dbase, qs.seqoffset,
           needed,
-          out.as<vsa_match>(), keys.as<uint64_t>(), packbits);
+          out.as<vsa_match>(), keys.as<uint64_t>(), packbits, valbits);
       VSA_HIP(hipGetLastError());
     }
     needed += nfirst;
@@ -1244,7 +1261,15 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     DevBuf mums;
     uint64_t nm = 0;
-    if (packed)
+    if (valbits != 0)
+    {
+      if (mumfilter_packed<uint32_t>(keys, out, needed, lenbits, dbbits,
+                                     stream, mums, &nm, &mumsum, 0, valbits,
+                                     qs.seqoffset))
+      {
+        return -100;
+      }
+    } else if (packed)
     {
       if (mumfilter_packed(keys, out, needed, lenbits, dbbits, stream, mums,
                            &nm, &mumsum))
