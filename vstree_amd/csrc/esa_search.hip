@@ -609,8 +609,8 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
       return -100;
     }
     k_mum_keyflags<<<gridfor(ncand), VSA_BLOCK, 0, stream>>>(
-        k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
-        lenbits, keep.as<uint8_t>());
+        k2.as<uint64_t>(), dbright.as<uint64_t>(), ncand, lenbits,
+        keep.as<uint8_t>());
     VSA_HIP(hipGetLastError());
     auto keepit =
         rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
@@ -699,10 +699,10 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
   {
     return 0;
   }
-  DevBuf k2, v2, ends, dbright, keep, slots, temp, dcount, blocksum;
+  DevBuf k2, v2, dbright, keep, slots, temp, dcount, blocksum;
   const size_t nblocks = gridfor(ncand);
   if (k2.alloc(ncand * 8) || v2.alloc(ncand * sizeof(VAL)) ||
-      ends.alloc(ncand * 8) || dbright.alloc(ncand * 8) ||
+      dbright.alloc(ncand * 8) ||
       keep.alloc(ncand) || slots.alloc(ncand * 4) || dcount.alloc(24) ||
       blocksum.alloc(nblocks * 8) || mums.alloc(ncand * sizeof(vsa_match)))
   {
@@ -729,32 +729,30 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     VSA_HIP(rocprim::radix_sort_pairs(
         temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<VAL>(),
         v2.as<VAL>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
-    k_mum_keyends<<<nblocks, VSA_BLOCK, 0, stream>>>(
-        k2.as<uint64_t>(), ncand, lenbits, ends.as<uint64_t>());
-    VSA_HIP(hipGetLastError());
+    // running maximum of the right ends, which are a function of the keys
+    auto ends = rocprim::make_transform_iterator(k2.as<uint64_t>(),
+                                                 KeyToRightEnd{lenbits});
     tb = 0;
-    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends.as<uint64_t>(),
-                                    dbright.as<uint64_t>(), carry,
-                                    (size_t) ncand, rocprim::maximum<uint64_t>(),
-                                    stream));
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, ends, dbright.as<uint64_t>(),
+                                    carry, (size_t) ncand,
+                                    rocprim::maximum<uint64_t>(), stream));
     if (temp.alloc(tb))
     {
       return -100;
     }
-    VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends.as<uint64_t>(),
-                                    dbright.as<uint64_t>(), carry,
-                                    (size_t) ncand, rocprim::maximum<uint64_t>(),
-                                    stream));
+    VSA_HIP(rocprim::exclusive_scan(temp.p, tb, ends, dbright.as<uint64_t>(),
+                                    carry, (size_t) ncand,
+                                    rocprim::maximum<uint64_t>(), stream));
     if (byruns)
     {
       k_mum_keyflags_runs<<<nblocks, VSA_BLOCK, 0, stream>>>(
-          k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
-          lenbits, keep.as<uint8_t>(), dcount.as<unsigned int>() + 4);
+          k2.as<uint64_t>(), dbright.as<uint64_t>(), ncand, lenbits,
+          keep.as<uint8_t>(), dcount.as<unsigned int>() + 4);
     } else
     {
       k_mum_keyflags<<<nblocks, VSA_BLOCK, 0, stream>>>(
-          k2.as<uint64_t>(), ends.as<uint64_t>(), dbright.as<uint64_t>(), ncand,
-          lenbits, keep.as<uint8_t>());
+          k2.as<uint64_t>(), dbright.as<uint64_t>(), ncand, lenbits,
+          keep.as<uint8_t>());
     }
     VSA_HIP(hipGetLastError());
     auto keepit =
