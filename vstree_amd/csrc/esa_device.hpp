@@ -496,14 +496,24 @@ struct DeepHit
   uint64_t ew;      // esa8[w]
   uint32_t lcpnext; // lcp byte of entry w+1 (0 if w = n)
   uint8_t leftsym;  // tis[suf[w]-1] (separator if suf[w] = 0)
+  bool notleftmax;  // see vsa_locate_deep, qleft
 };
 
 template <int AHEAD = 1>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
-                uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu)
+                uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
+                uint32_t qleft = 0x100u)
 {
+  // qleft < 0x100 (MEM enumeration): the query symbol in front of this
+  // suffix.  In a bucket of one suffix that suffix is the only one sharing D
+  // or more symbols with the query; if the text symbol in front of it equals
+  // qleft the match is not left maximal and nothing will be reported for
+  // this work-item whatever its length (leftrightsubmatch, fquery.c:139-270
+  // -> PROCESSSUFFIX :54-81): hit.notleftmax is set and the comparison on
+  // the text -- the expensive part for reads that match end to end at every
+  // offset -- is skipped.  maxlcp is then only a lower bound.
   // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
   // of at least this length (the MUM test); the default never fetches it --
   // it is a random text access of its own for every non-empty bucket.
@@ -752,9 +762,16 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   }
   // the symbol in front of the located suffix (left maximality) travels
   // with the first text words: one round trip less.  Front pad = separator.
+  hit.notleftmax = false;
   if (state == VSA_LOC_FOUND && (extend || maxlcp >= needleft))
   {
     hit.leftsym = ix.tis[(int64_t) (hit.ew & 0xFFFFFFFFull) - 1];
+    if (qleft < 0x100u && cnt == 1 && !VSA_ISSPECIAL((uint8_t) qleft) &&
+        (hit.ew & 0xFFFFFFFFull) != 0 && hit.leftsym == (uint8_t) qleft)
+    {
+      hit.notleftmax = true;
+      extend = false;
+    }
   }
   // one text comparison for the lanes with a tie, all at the same time
   if (extend)
