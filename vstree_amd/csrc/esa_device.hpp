@@ -14,8 +14,9 @@
 //                    suf/tis.  Probe for probe the reference's algorithm.
 //   deep locate      an internal, deeper bucket table (bck2, D symbols, about
 //                    one to three suffixes per bucket) + the keyed array esa8
-//                    {suf:32, lcp byte:8, key:22 = the 11 symbols behind the
-//                    first D, flag:1}: a short, wavefront-uniform search on
+//                    {suf:32, lcp byte:8, key:20 = the 10 symbols behind the
+//                    first D, the symbol in FRONT of the suffix:2, flag:1,
+//                    left-is-special:1}: a short, wavefront-uniform search on
 //                    keys, then ONE text comparison for the lanes whose key
 //                    ties.  ~10 dependent steps instead of ~140, ~3 random
 //                    64-byte sectors instead of ~15.
@@ -515,8 +516,7 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   // the text -- the expensive part for reads that match end to end at every
   // offset -- is skipped.  maxlcp is then only a lower bound.
   // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
-  // of at least this length (the MUM test); the default never fetches it --
-  // it is a random text access of its own for every non-empty bucket.
+  // of at least this length (the MUM test).
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
@@ -765,7 +765,11 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   hit.notleftmax = false;
   if (state == VSA_LOC_FOUND && (extend || maxlcp >= needleft))
   {
-    hit.leftsym = ix.tis[(int64_t) (hit.ew & 0xFFFFFFFFull) - 1];
+    // the symbol in front of the located suffix travels in its entry: the
+    // left maximality tests cost no access to the text
+    hit.leftsym = (hit.ew & VSA_LEFTSPECIAL) != 0
+                      ? (uint8_t) VSA_SEPARATOR
+                      : (uint8_t) ((hit.ew >> VSA_LEFTSHIFT) & 3u);
     if (qleft < 0x100u && cnt == 1 && !VSA_ISSPECIAL((uint8_t) qleft) &&
         (hit.ew & 0xFFFFFFFFull) != 0 && hit.leftsym == (uint8_t) qleft)
     {

@@ -1518,8 +1518,12 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
     }
     key = (key << 2) | (a & 3);
   }
+  // front pad of the text = separator: suffix 0 has nothing in front
+  const uint8_t l = tis[(int64_t) s - 1];
+  const uint64_t left = VSA_ISSPECIAL(l) ? VSA_LEFTSPECIAL
+                                         : ((uint64_t) (l & 3) << VSA_LEFTSHIFT);
   esa8[j] = (uint64_t) s | ((uint64_t) lcp[j] << 32) |
-            (key << VSA_KEYSHIFT) | flag;
+            (key << VSA_KEYSHIFT) | flag | left;
 }
 
 // slot16[code] = (bck2 pair, first entry of the bucket)

@@ -55,9 +55,11 @@ struct DevIndex
   const IDX *bck;     // [2*numofcodes]
   const uint8_t *bwt; // [n+1] or nullptr
   // Deep locate (esa_device.hpp), DNA alphabets with 32-bit suf only:
-  // esa8 [n+1] per suffix {suf:32 | lcp byte:8 | key:22 | flag:1}, key = the
-  // VSA_KEYSYMS symbols behind the first D ones, 2 bits each, first symbol
-  // most significant, flag = a special symbol in that window;
+  // esa8 [n+1] per suffix {suf:32 | lcp byte:8 | key:20 | left:2 | flag:1 |
+  // leftspecial:1}, key = the VSA_KEYSYMS symbols behind the first D ones, 2
+  // bits each, first symbol most significant, flag = a special symbol in that
+  // window; left = the symbol in front of the suffix, leftspecial = that one
+  // is a wildcard / separator or the suffix starts the text;
   // bck2 [2*4^D] (left, mid) pairs like bck, for D >= pl symbols.
   const uint64_t *esa8;
   const uint32_t *bck2;
@@ -71,10 +73,12 @@ struct DevIndex
   uint32_t tune; // experiment switches (VSA_TUNE), see esa_search.hip
 };
 
-#define VSA_KEYSYMS 11u
+#define VSA_KEYSYMS 10u
 #define VSA_KEYSHIFT 40u
-#define VSA_KEYMASK 0x3FFFFFu
+#define VSA_KEYMASK 0xFFFFFu
+#define VSA_LEFTSHIFT 60u            // two bits: the symbol in front of the suffix
 #define VSA_KEYFLAG (1ull << 62)
+#define VSA_LEFTSPECIAL (1ull << 63) // ... is not a regular one / does not exist
 
 struct vsa_index
 {
