@@ -507,14 +507,16 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
                 uint32_t qleft = 0x100u)
 {
-  // qleft < 0x100 (MEM enumeration): the query symbol in front of this
-  // suffix.  In a bucket of one suffix that suffix is the only one sharing D
-  // or more symbols with the query; if the text symbol in front of it equals
-  // qleft the match is not left maximal and nothing will be reported for
-  // this work-item whatever its length (leftrightsubmatch, fquery.c:139-270
-  // -> PROCESSSUFFIX :54-81): hit.notleftmax is set and the comparison on
-  // the text -- the expensive part for reads that match end to end at every
-  // offset -- is skipped.  maxlcp is then only a lower bound.
+  // qleft < 0x100 (MEM enumeration, needleft = the least length): the query
+  // symbol in front of this suffix.  Only members of the deep bucket share D
+  // or more symbols with the query; in a bucket of up to four their keys tell
+  // which of them can reach the least length.  If every one of those has
+  // qleft in front (the symbol is in the entry), no match of this work-item
+  // is left maximal and nothing will be reported whatever the lengths
+  // (leftrightsubmatch, fquery.c:139-270 -> PROCESSSUFFIX :54-81):
+  // hit.notleftmax is set and the comparison on the text -- the expensive
+  // part for reads that match end to end at every offset -- is skipped.
+  // maxlcp is then only a lower bound.
   // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
   // of at least this length (the MUM test).
   const bool nt = (ix.tune & 1u) != 0;
@@ -631,6 +633,10 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   // than the query's
   uint32_t lo = 0;
   bool flagged = false;
+  // qleft: is there a member of the bucket that shares enough symbols with
+  // the query to be reported, and do all such members have qleft in front?
+  bool anylong = false, allnotleft = true;
+  const uint32_t enough = needleft < D + limit ? needleft : D + limit;
   if (small)
   {
 #pragma unroll
@@ -642,6 +648,15 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
         const uint32_t tk =
             ((uint32_t) (e[i] >> VSA_KEYSHIFT) & VSA_KEYMASK) >> ksh;
         lo += (tk < qk) ? 1u : 0u;
+        if (qleft < 0x100u)
+        {
+          const bool islong = D + vsa_keylcp(tk, qk, limit) >= enough;
+          const bool sameleft =
+              (e[i] & VSA_LEFTSPECIAL) == 0 &&
+              (uint32_t) ((e[i] >> VSA_LEFTSHIFT) & 3u) == qleft;
+          anylong = anylong || islong;
+          allnotleft = allnotleft && (!islong || sameleft);
+        }
       }
     }
   }
@@ -770,8 +785,7 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     hit.leftsym = (hit.ew & VSA_LEFTSPECIAL) != 0
                       ? (uint8_t) VSA_SEPARATOR
                       : (uint8_t) ((hit.ew >> VSA_LEFTSHIFT) & 3u);
-    if (qleft < 0x100u && cnt == 1 && !VSA_ISSPECIAL((uint8_t) qleft) &&
-        (hit.ew & 0xFFFFFFFFull) != 0 && hit.leftsym == (uint8_t) qleft)
+    if (qleft < 0x100u && small && anylong && allnotleft)
     {
       hit.notleftmax = true;
       extend = false;
