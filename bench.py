@@ -297,17 +297,27 @@ def main():
             "note": "algorithmic bytes = SURVEY 8d formula counted by the "
                     "instrumented CPU restatement (7.1 kB per 100 bp query "
                     "for all 81 suffixes) scaled to the %.1f%% of the "
-                    "suffix searches this kernel executes after the anchor "
-                    "pass and the work plan; the path is random 8-byte "
+                    "suffix searches this kernel executes after the first "
+                    "pass and the work plan; the path is random 8/16-byte "
                     "reads, one 64-byte sector each (traffic/algorithmic "
-                    "~ 1.75), see DESIGN.md"
-                    % (100.0 * main_searches / world / full_searches)}
+                    "~ %.2f), see DESIGN.md"
+                    % (100.0 * main_searches / world / full_searches,
+                       (traffic or 0) / executed_bytes_launch)}
         if world == 1 and a.cpu_sample > 0:
             host.sti1 = index.make_sti1()
             sample = H.Queries.uniform(qsym[:a.cpu_sample * m], m)
             t0 = time.perf_counter()
             ref = H.oracle_querymatches(host, sample, L, mum=True, speedup=2)
             dt = time.perf_counter() - t0
+            # the same sample as a batch of its own on the GPU: identical list
+            gsample = V.Queries.from_host(sample.symbols, sample.start,
+                                          sample.length, dev)
+            gres = V.findquerymatches(index, gsample, L, mum=True)
+            same = bool(np.array_equal(gres.fetch(), ref))
+            gres.close()
+            if not same:
+                raise RuntimeError("bench.py: GPU and CPU oracle disagree on "
+                                   "the %d-query sample" % sample.nq)
             out["cpu_baseline"] = {
                 "value": sample.nq / dt, "unit": "queries/s", "cores": 1,
                 "kind": "port",
@@ -315,7 +325,8 @@ def main():
                           "index (32-bit tables), oracle/vsoracle.c "
                           "algorithm 2 = the reference's default -qspeedup 2 "
                           "incl. the MUM filter, %.1f s, %d MUMs"
-                          % (sample.nq, dt, len(ref))}
+                          % (sample.nq, dt, len(ref)),
+                "gpu_list_equal_on_sample": same}
             # the real reference program, timed once on a GPU box on the
             # same index and sample size (scripts/cpu_reference_probe.py)
             rpath = os.path.join(ROOT, "profiles", "cpu_reference.json")
