@@ -157,7 +157,7 @@ uint64_t powu64(uint64_t b, uint32_t e)
 // filled by the caller (upload or the GPU builder)
 int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
                     uint64_t nllv, bool withbwt, int device,
-                    vsa_index **out)
+                    vsa_index **out, bool mayforcewide)
 {
   if (vsa_set_device(device) != 0)
   {
@@ -176,8 +176,9 @@ int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
   {
     // VSA_FORCE_WIDE=1: 64-bit device tables whatever the length (tests of
     // the wide instantiations on small inputs)
+    // (not for the GPU builder, which writes 32-bit tables)
     const char *wide = getenv("VSA_FORCE_WIDE");
-    if (wide != nullptr && strcmp(wide, "1") == 0)
+    if (mayforcewide && wide != nullptr && strcmp(wide, "1") == 0)
     {
       ix->isize = 8;
     }

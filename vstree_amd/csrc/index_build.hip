@@ -784,7 +784,7 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
   }
   vsa_index *ix = nullptr;
   int rc = vsa_index_alloc(totallength, prefixlength, numofchars, 0, true,
-                           device, &ix);
+                           device, &ix, false);
   if (rc != 0)
   {
     vsa_index_close(ix);

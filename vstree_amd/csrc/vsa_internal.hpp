@@ -203,6 +203,9 @@ int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
                            hipStream_t stream);
 
 // device tables of the given shape, contents undefined (api.hip)
+// mayforcewide: VSA_FORCE_WIDE=1 may make the tables 64 bits wide (uploads of
+// host tables; the GPU builder writes 32-bit tables and says false)
 int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
-                    uint64_t nllv, bool withbwt, int device, vsa_index **out);
+                    uint64_t nllv, bool withbwt, int device, vsa_index **out,
+                    bool mayforcewide = true);
 
