@@ -5,7 +5,7 @@
 //   search_complete.inc  K1  k_complete_search   one work-item per query:
 //                            locate -> lcptab widening -> suffix-array
 //                            interval [left, left+count)
-//                            k_complete_expand   one work-item per match
+//                            k_complete_expand   one workgroup per 256 queries
 //   search_query.inc     K2  k_query_search      one work-item per (query,
 //                            offset): locate -> MEM enumeration or
 //                            MUM-candidate test; wavefront-aggregated append
@@ -390,7 +390,7 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
     {
       return -100;
     }
-    k_complete_expand<IDX><<<gridfor(total), VSA_BLOCK, 0, stream>>>(
+    k_complete_expand<IDX><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
         ix, qs, qlimit, left.as<uint64_t>(), offsets.as<uint64_t>(), total,
         matches.as<vsa_match>());
     VSA_HIP(hipGetLastError());
