@@ -292,22 +292,75 @@ unsigned int bitsfor(uint64_t maxvalue)
   return b;
 }
 
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_iota_u32(uint32_t *__restrict__ out, uint64_t n)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t < n)
+  {
+    out[t] = (uint32_t) t;
+  }
+}
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_gather_matches(const vsa_match *__restrict__ in,
+                 const uint32_t *__restrict__ order, uint64_t n,
+                 vsa_match *__restrict__ out)
+{
+  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (t < n)
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + order[t]);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + t);
+    const uint4 lo = src[0], hi = src[1];
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+}
+
 // stable sort of (key, match) pairs by key bits [0, endbit); results land in
-// keys_out / matches_out
+// keys_out / matches_out.  The 32-byte records do not travel through the
+// radix passes: (key, index) pairs do, and one gather follows.
 int sortbykey(uint64_t *keys_in, uint64_t *keys_out, vsa_match *in,
               vsa_match *out, uint64_t n, unsigned int endbit,
               hipStream_t stream)
 {
   DevBuf temp;
   size_t tb = 0;
-  VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, in, out,
-                                    (size_t) n, 0u, endbit, stream));
+  if (n >= 0xFFFFFFFFull)
+  {
+    VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, in, out,
+                                      (size_t) n, 0u, endbit, stream));
+    if (temp.alloc(tb) != 0)
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, keys_in, keys_out, in, out,
+                                      (size_t) n, 0u, endbit, stream));
+    return 0;
+  }
+  DevBuf order, order2;
+  if (order.alloc(n * 4 + 4) || order2.alloc(n * 4 + 4))
+  {
+    return -100;
+  }
+  k_iota_u32<<<gridfor(n), VSA_BLOCK, 0, stream>>>(order.as<uint32_t>(), n);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out,
+                                    order.as<uint32_t>(),
+                                    order2.as<uint32_t>(), (size_t) n, 0u,
+                                    endbit, stream));
   if (temp.alloc(tb) != 0)
   {
     return -100;
   }
-  VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, keys_in, keys_out, in, out,
-                                    (size_t) n, 0u, endbit, stream));
+  VSA_HIP(rocprim::radix_sort_pairs(temp.p, tb, keys_in, keys_out,
+                                    order.as<uint32_t>(),
+                                    order2.as<uint32_t>(), (size_t) n, 0u,
+                                    endbit, stream));
+  k_gather_matches<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+      in, order2.as<uint32_t>(), n, out);
+  VSA_HIP(hipGetLastError());
   return 0;
 }
 
