@@ -880,21 +880,44 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     nitems = (uint64_t) perquery * queries->nq;
   } else
   {
-    std::vector<uint64_t> hb(queries->nq + 1);
-    for (uint64_t q = 0; q < queries->nq; q++)
-    {
-      hb[q] = nitems;
-      const uint64_t len = queries->hlength[q];
-      nitems += (len >= searchlength) ? len - searchlength + 1 : 0;
-    }
-    hb[queries->nq] = nitems;
-    if (base.alloc(hb.size() * 8))
+    // base[q] = number of work-items in front of query q, from the lengths
+    // on the device (a host loop and an upload of 8 bytes per query cost
+    // more than the search for a batch of millions of reads)
+    const uint64_t nqr = queries->nq;
+    DevBuf btemp;
+    size_t tb = 0;
+    const uint64_t least = searchlength;
+    auto items = rocprim::make_transform_iterator(
+        rocprim::counting_iterator<uint64_t>(0),
+        [len = qs.length, nqr, least] __device__(uint64_t q) -> uint64_t {
+          if (q >= nqr)
+          {
+            return 0; // the entry behind the last query: the total
+          }
+          const uint64_t l = len[q];
+          return l >= least ? l - least + 1 : 0;
+        });
+    if (base.alloc((nqr + 1) * 8))
     {
       return -100;
     }
-    VSA_HIP(hipMemcpyAsync(base.p, hb.data(), hb.size() * 8,
-                           hipMemcpyHostToDevice, stream));
-    VSA_HIP(hipStreamSynchronize(stream));
+    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, items, base.as<uint64_t>(),
+                                    (uint64_t) 0, (size_t) (nqr + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    if (btemp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::exclusive_scan(btemp.p, tb, items, base.as<uint64_t>(),
+                                    (uint64_t) 0, (size_t) (nqr + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    {
+      const Fetch f = {base.as<uint64_t>() + nqr, 8};
+      if (fetchwords(stream, &f, 1, &nitems))
+      {
+        return -100;
+      }
+    }
     dbase = base.as<uint64_t>();
   }
   res->stats.searches = nitems;
