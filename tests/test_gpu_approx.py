@@ -162,3 +162,37 @@ def test_region_scan_and_banded_alignment_agree(V, monkeypatch):
     b = V.findapproxcompletematches(gi, gpu_queries(V, q), True, 2).fetch()
     assert len(a) == M["c1"]["runs"]["approx_e2"]["lines"]
     assert np.array_equal(a, b)
+
+
+def test_many_reads_of_different_lengths_are_planned_per_length(V):
+    """beyond 4096 reads of mixed lengths the thresholds and piece geometry
+    come from per-length tables filled on the device (apm_plan, bylength);
+    the list must be the oracle's"""
+    rng = np.random.default_rng(2024)
+    n = 150000
+    tis = rng.integers(0, 4, n).astype(np.uint8)
+    gi = V.Index.build(tis, 4, 0)
+    t = gi.download()
+    host = H.Index(n, gi.info().prefixlength, 4, t["tis"], t["suf"],
+                   t["lcp"], t["llv"], t["bck"], t["bwt"], None)
+    reads = []
+    for i in range(6000):
+        m = int(rng.integers(90, 151))
+        p = int(rng.integers(0, n - m))
+        q = tis[p:p + m].copy()
+        for e in range(int(rng.integers(0, 4))):
+            kind, x = int(rng.integers(0, 3)), int(rng.integers(0, len(q)))
+            if kind == 0:
+                q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4
+            elif kind == 1:
+                q = np.delete(q, x)
+            else:
+                q = np.insert(q, x, rng.integers(0, 4))
+        reads.append(q.astype(np.uint8))
+    q = H.Queries.from_list(reads)
+    for doedist, k in ((True, 2), (False, 2), (True, 3)):
+        want = H.oracle_approx(host, q, doedist, k)
+        got = V.findapproxcompletematches(gi, gpu_queries(V, q), doedist,
+                                          k).fetch()
+        assert len(want) > 1000
+        assert np.array_equal(got, want), (doedist, k)
