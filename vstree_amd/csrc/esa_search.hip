@@ -14,9 +14,11 @@
 //   mum_workplan.inc     K2a k_mum_first / k_mum_plan / k_expand_plan (and
 //                            the older k_mum_anchor): which offsets of a
 //                            query can be MUM candidates at all
-//   mum_filter.inc       K4  candidates sorted by (dbstart asc, length desc),
-//                            prefix-max scan, flag, ordered compaction
-//                            (kurtz/cleanMUMcand.c:55-118)
+//   mum_filter.inc       K4  candidates as (sort key, value) pairs sorted by
+//                            dbstart, prefix-max scan of the right ends,
+//                            flags from the keys (runs of equal dbstarts
+//                            looked at as runs), survivors written as records
+//                            in order (kurtz/cleanMUMcand.c:55-118)
 //   selfmum_scan.inc     K3  k_selfmum_peaks / k_selfmum_emit: streaming scan
 //                            over lcptab + bwttab for indexes that hold
 //                            their queries (Vmengine/fmumself.c:10-66)
@@ -31,6 +33,9 @@
 //            bit 1  no MUM work reduction at all (every offset is searched)
 //            bit 2  no work plan (anchor pass only)
 //            bit 3  anchor pass + plan instead of first pass + plan
+//            bit 4  MUM candidates as 32-byte records through the filter
+//                   (instead of pairs)
+//            bit 5  8-byte values in the pairs (instead of 4-byte ones)
 //            bits 8..19  workgroup size of K2 (64, 128, 256, 512)
 //   VSA_NO_ESA8=1, VSA_DEEP_PREFIX=D   the keyed search array off / its depth
 #include <cstring>
