@@ -134,6 +134,15 @@ int vsa_index_make_sti1(const vsa_index *index, uint8_t *sti1);
    file -- so that vsa_findmaximaluniquematches can run on it */
 int vsa_index_set_queryseparator(vsa_index *index, uint64_t querysepposition);
 
+/* Matchparam.queryspeedup (Vmengine/mparms.h:53, `vmatch -qspeedup`): which
+   of the reference's algorithms the MEM lists (`-l L -q`) follow in their
+   order inside one query offset -- 0 = matchquerysubstring0
+   (kurtz/matchsub.c:165), 2 = matchquerysubstring2 (:353), the reference's
+   default and the default here.  The set of matches is the same; complete
+   matches, MUMs and MUM candidates do not depend on it.  Other values are an
+   error ("illegal speedup value", Vmengine/fquery.c:433). */
+int vsa_index_set_queryspeedup(vsa_index *index, uint32_t queryspeedup);
+
 /* copies the device tables back to host buffers sized by the caller from
    vsa_index_getinfo (entries of suf/bck/llv have device_integersize bits);
    NULL pointers are skipped */
@@ -317,8 +326,9 @@ int vsa_findapproxcompletematches(const vsa_index *index,
   searchlength is Matchparam.seedlength (Vmatch/matchlenparm.c:17-22); a
   value below prefixlength is the reference's error (fquery.c:440-446).
   Order: MEM and candidates by query, query offset, then witness / left /
-  right like kurtz/matchsub.c:165-235 with Vmengine/fquery.c:139-270 (the
-  order of vmatch -qspeedup 0); MUMs by ascending dbstart
+  right like kurtz/matchsub.c with Vmengine/fquery.c:139-270 (the witness is
+  that of the reference's default algorithm 2, or of algorithm 0 after
+  vsa_index_set_queryspeedup(index, 0)); MUMs by ascending dbstart
   (kurtz/cleanMUMcand.c:55-118).
 */
 int vsa_findquerymatches(const vsa_index *index, const vsa_queries *queries,

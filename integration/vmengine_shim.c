@@ -5,10 +5,13 @@
   src/Vmengine) and linked into vmatch together with libvstree_amd.so using
 
       -Wl,--wrap=findcompletematches -Wl,--wrap=findquerymatches
-      -Wl,--wrap=findmaximaluniquematches
+      -Wl,--wrap=findmaximaluniquematches -Wl,--wrap=findsupermax
+      -Wl,--wrap=vmatmaxout4 -Wl,--wrap=vmatmaxout12 -Wl,--wrap=vmatmaxout21
+      -Wl,--wrap=vmatmaxout31 -Wl,--wrap=findtandems
 
-  so that every call site in src/Vmatch/runquery.c:97-115,149-169 and
-  src/Vmengine/fself.c:223 lands here unchanged.  Exact matching on the
+  (the nine wraps of integration/Makefile) so that every call site in
+  src/Vmatch/runquery.c:97-115,149-169 and src/Vmengine/fself.c:203-260
+  lands here unchanged.  Exact matching on the
   index goes to the GPU; every other mode (-online, -e/-h/-xdrop, plugin
   index, protein-vs-DNA, ...) is handed to the reference's own function
   (__real_...), so this is a drop-in for the one path and nothing else.
@@ -326,8 +329,11 @@ Sint __wrap_findquerymatches(Virtualtree *virtualtree,
   vsa_queries *queries;
   int rc;
 
+  /* -qspeedup 0 and 2 (the documented levels, Vmatch/parsevm.c:781-784) are
+     reproduced in their own order; the undocumented 3..5 stay on the CPU */
   if (!usegpu() || !MPARMEXACTMATCH(&matchparam->maxdist) ||
       matchparam->xdropbelowscore != UNDEFXDROPBELOWSCORE ||
+      (matchparam->queryspeedup != 0 && matchparam->queryspeedup != 2) ||
       virtualtree->suftab == NULL || virtualtree->bcktab == NULL ||
       virtualtree->lcptab == NULL)
   {
@@ -351,6 +357,8 @@ Sint __wrap_findquerymatches(Virtualtree *virtualtree,
   {
     return (Sint) -1;
   }
+  (void) vsa_index_set_queryspeedup(index,
+                                    (uint32_t) matchparam->queryspeedup);
   rc = vsa_findquerymatches_cb(index, queries, domaximaluniquematch ? 1 : 0,
                                domaximaluniquematchcandidates ? 1 : 0,
                                matchparam->seedlength, querysink,

@@ -62,10 +62,13 @@ def run_gpu(V, case, key, bits=64):
     return H.matches_as_ref(idx, V.findquerymatches(gi, gq, L, **kw).fetch())
 
 
-# MEM order on the GPU is the order of vmatch -qspeedup 0 (algorithm 0); the
-# default algorithm 2 reports the same set, possibly in another order inside
-# one query offset -- so only the _sp0 MEM lists are compared in order, the
-# other MEM lists as sets; complete / MUM / candidate lists always in order
+# MEM order inside one query offset depends on the reference's algorithm
+# (vmatch -qspeedup 0 | 2): the GPU reproduces both, every list is compared in
+# order
+# (mode, -qspeedup level): MEM lists under both algorithms, the lists that do
+# not depend on the algorithm once
+MODES = [({}, 0), ({}, 2), (dict(mum=True, cand=True), 2), (dict(mum=True), 2)]
+
 CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
          if not k.endswith("_short") and "strands" not in M[c]["runs"][k]
          and not k.startswith("approx_")]   # those: tests/test_gpu_approx.py
@@ -73,15 +76,13 @@ CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
 
 @pytest.mark.parametrize("case,key", CASES)
 def test_gpu_reproduces_reference_output(V, case, key):
+    # lists recorded with -qspeedup 0 carry _sp0 in their name, all others come
+    # from the reference's default algorithm 2: both are reproduced in order
+    gpu_index(V, case, 64).set_queryspeedup(0 if key.endswith("_sp0") else 2)
     got = run_gpu(V, case, key)
     want = H.expected(case, key)
     assert len(got) == len(want)
-    if (key.startswith("mem") or key.startswith("palindromic")) and \
-            not key.endswith("_sp0"):
-        # recorded with the reference's default algorithm 2
-        assert np.array_equal(H.sorted_matches(got), H.sorted_matches(want))
-    else:
-        assert np.array_equal(got, want)
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("case", ["micro", "grumbach", "largepat"])
@@ -95,10 +96,10 @@ def test_gpu_equals_oracle_32bit_tables(V, case):
                           H.oracle_complete(idx, q)
                           if q.length.min() >= pl else np.zeros(0))
     L = max(pl, 8 if case != "micro" else 2)
-    for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
-        a = V.findquerymatches(gi, gq, L, **kw).fetch()
-        b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
-        assert np.array_equal(a, b), (case, kw)
+    for kw, sp in MODES:
+        a = V.findquerymatches(gi, gq, L, speedup=sp, **kw).fetch()
+        b = H.oracle_querymatches(idx, q, L, speedup=sp, **kw)
+        assert np.array_equal(a, b), (case, kw, sp)
 
 
 def test_largepat_known_answer_file_gpu(V):
@@ -119,10 +120,9 @@ def test_short_query_is_the_references_hard_error(V):
     got = H.matches_as_ref(idx, e.value.partial.fetch())
     assert np.array_equal(got, H.expected("grumbach", "complete_short"))
     # -l skips the short query silently
-    got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 8).fetch())
-    assert np.array_equal(H.sorted_matches(got),
-                          H.sorted_matches(H.expected("grumbach",
-                                                      "mem8_short")))
+    got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 8,
+                                                   speedup=2).fetch())
+    assert np.array_equal(got, H.expected("grumbach", "mem8_short"))
     # searchlength below prefixlength: fquery.c:440-446
     with pytest.raises(V.VsaError) as e:
         V.findquerymatches(gi, gq, 5)
@@ -147,8 +147,8 @@ def test_empty_and_degenerate_batches(V):
 def test_callback_delivery_order_and_stop(V):
     idx, q = H.load_case("grumbach")
     gi, gq = gpu_index(V, "grumbach"), gpu_queries(V, q)
-    want = H.oracle_querymatches(idx, q, 14, speedup=0)
-    rc, got = V.findquerymatches_cb(gi, gq, 14)
+    want = H.oracle_querymatches(idx, q, 14, speedup=2)
+    rc, got = V.findquerymatches_cb(gi, gq, 14, speedup=2)
     assert rc == 0
     assert got == [tuple(int(x) for x in r) for r in want.tolist()]
     # a non-zero return of the callback stops the run (procexqu.c:61-64)
@@ -223,10 +223,10 @@ def test_random_ragged_queries_with_wildcards(V):
     assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
                           H.oracle_complete(idx, q))
     L = idx.prefixlength + 3
-    for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
-        assert np.array_equal(V.findquerymatches(gi, gq, L, **kw).fetch(),
-                              H.oracle_querymatches(idx, q, L, speedup=0,
-                                                    **kw)), kw
+    for kw, sp in MODES:
+        assert np.array_equal(
+            V.findquerymatches(gi, gq, L, speedup=sp, **kw).fetch(),
+            H.oracle_querymatches(idx, q, L, speedup=sp, **kw)), (kw, sp)
 
 
 def test_repeats_beyond_255_and_many_occurrences(V):
@@ -247,10 +247,10 @@ def test_repeats_beyond_255_and_many_occurrences(V):
     assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
                           H.oracle_complete(idx, q))
     for L in (8, 260):
-        for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
-            a = V.findquerymatches(gi, gq, L, **kw).fetch()
-            b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
-            assert np.array_equal(a, b), (L, kw)
+        for kw, sp in MODES:
+            a = V.findquerymatches(gi, gq, L, speedup=sp, **kw).fetch()
+            b = H.oracle_querymatches(idx, q, L, speedup=sp, **kw)
+            assert np.array_equal(a, b), (L, kw, sp)
 
 
 @pytest.mark.parametrize("mode", ["reference_walk", "deep7", "deep9",
@@ -270,15 +270,16 @@ def test_both_locate_strategies_give_the_same_lists(V, mode, monkeypatch):
     gq = gpu_queries(V, q)
     got = H.matches_as_ref(idx, V.findcompletematches(gi, gq).fetch())
     assert np.array_equal(got, H.expected("c1", "complete"))
-    for key, kw in (("mem20_sp0", {}), ("mumcand20", dict(mum=True,
-                                                          cand=True)),
+    for key, kw in (("mem20_sp0", dict(speedup=0)), ("mem20_sp2", dict(speedup=2)),
+                    ("mumcand20", dict(mum=True, cand=True)),
                     ("mum20", dict(mum=True))):
         got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
                                                        **kw).fetch())
         assert np.array_equal(got, H.expected("c1", key)), (mode, key)
     # a search length below the deep prefix falls back by itself
-    a = V.findquerymatches(gi, gq, 8).fetch()
-    assert np.array_equal(a, H.oracle_querymatches(idx, q, 8, speedup=0))
+    for sp in (0, 2):
+        a = V.findquerymatches(gi, gq, 8, speedup=sp).fetch()
+        assert np.array_equal(a, H.oracle_querymatches(idx, q, 8, speedup=sp))
 
 
 def test_deep_locate_on_repeats_and_ties(V):
@@ -309,10 +310,10 @@ def test_deep_locate_on_repeats_and_ties(V):
     assert np.array_equal(V.findcompletematches(gi, gq).fetch(),
                           H.oracle_complete(idx, q))
     for L in (6, 7, 9, 12, 18, 25):
-        for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
-            a = V.findquerymatches(gi, gq, L, **kw).fetch()
-            b = H.oracle_querymatches(idx, q, L, speedup=0, **kw)
-            assert np.array_equal(a, b), (L, kw)
+        for kw, sp in MODES:
+            a = V.findquerymatches(gi, gq, L, speedup=sp, **kw).fetch()
+            b = H.oracle_querymatches(idx, q, L, speedup=sp, **kw)
+            assert np.array_equal(a, b), (L, kw, sp)
 
 
 def test_mum_filter_in_dbstart_ranges_equals_whole_filter(V):
@@ -573,12 +574,9 @@ def test_wide_device_tables(V, case, monkeypatch):
                 L = int("".join(ch for ch in name if ch.isdigit()))
                 got = H.matches_as_ref(idx, V.findquerymatches(
                     gi, gq, L, mum=name.startswith("mum"),
-                    cand="cand" in name).fetch())
-        if key.startswith("mem") and not key.endswith("_sp0"):
-            assert np.array_equal(H.sorted_matches(got),
-                                  H.sorted_matches(want)), (case, key)
-        else:
-            assert np.array_equal(got, want), (case, key)
+                    cand="cand" in name,
+                    speedup=0 if key.endswith("_sp0") else 2).fetch())
+        assert np.array_equal(got, want), (case, key)
 
 
 @pytest.mark.parametrize("tune", [2, 4, 8, 16, 32])

@@ -34,7 +34,9 @@ def test_gpu_matches_through_the_sink_equal_vmatch_stdout(V, case, key):
         name = key.partition("_sp")[0]
         least = int("".join(ch for ch in name if ch.isdigit()))
         m = V.findquerymatches(gi, gq, least, mum=name.startswith("mum"),
-                               cand="cand" in name).fetch()
+                               cand="cand" in name,
+                               speedup=0 if key.endswith("_sp0") else 2
+                               ).fetch()
         kind = V.SINK_QUERY
     text = query_sink(idx, q, kind, leastlength=least).format(m)
     assert text.count(b"\n") == run["lines"]

@@ -117,6 +117,7 @@ def _load():
         "vsa_index_build_device": (I, [V, U64, U32, U32, I, PP]),
         "vsa_index_download": (I, [V, V, V, V, V, V, V]),
         "vsa_index_set_queryseparator": (I, [V, U64]),
+        "vsa_index_set_queryspeedup": (I, [V, U32]),
         "vsa_mkvtree": (I, [C.POINTER(C.c_char_p), U32, C.POINTER(C.c_char_p),
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
@@ -270,6 +271,10 @@ class Index:
     def set_queryseparator(self, pos):
         _check(lib.vsa_index_set_queryseparator(self._h, int(pos)))
 
+    def set_queryspeedup(self, level):
+        """vmatch -qspeedup: 0 or 2 (default), the order of MEM lists."""
+        _check(lib.vsa_index_set_queryspeedup(self._h, int(level)))
+
     def make_sti1(self):
         out = np.zeros(self.info().totallength + 1, np.uint8)
         _check(lib.vsa_index_make_sti1(self._h, _ptr(out)))
@@ -415,8 +420,12 @@ def findapproxcompletematches(index, queries, doedist, distvalue,
     return res
 
 
-def findquerymatches(index, queries, searchlength, mum=False, cand=False):
-    """vmatch [-mum [cand]] -l L -q (Vmengine/fquery.c:1009)."""
+def findquerymatches(index, queries, searchlength, mum=False, cand=False,
+                     speedup=None):
+    """vmatch [-mum [cand]] -l L -q (Vmengine/fquery.c:1009); speedup = the
+    -qspeedup level (0 or 2) to set on the index first."""
+    if speedup is not None:
+        index.set_queryspeedup(speedup)
     h = C.c_void_p()
     _check(lib.vsa_findquerymatches(index._h, queries._h, int(mum),
                                     int(cand), int(searchlength),
@@ -530,7 +539,9 @@ def findapproxcompletematches_cb(index, queries, doedist, distvalue,
 
 
 def findquerymatches_cb(index, queries, searchlength, mum=False, cand=False,
-                        stop_after=None):
+                        stop_after=None, speedup=None):
+    if speedup is not None:
+        index.set_queryspeedup(speedup)
     got, cb = _collector(stop_after)
     rc = lib.vsa_findquerymatches_cb(index._h, queries._h, int(mum),
                                      int(cand), int(searchlength), cb, None)

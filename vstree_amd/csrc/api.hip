@@ -173,6 +173,7 @@ int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
   ix->numofcodes = powu64(numofchars, pl);
   ix->isize = (n + 1 <= 0xFFFFFFFFull) ? 4 : 8;
   ix->lcpquirk = -1;
+  ix->qspeedup = 2; // the reference's default, Vmengine/mparms.h:53
   {
     // VSA_FORCE_WIDE=1: 64-bit device tables whatever the length (tests of
     // the wide instantiations on small inputs)
@@ -375,6 +376,19 @@ extern "C" int vsa_index_set_queryseparator(vsa_index *ix,
   }
   ix->querysepposition = querysepposition;
   ix->hasindexedqueries = 1;
+  return 0;
+}
+
+extern "C" int vsa_index_set_queryspeedup(vsa_index *ix, uint32_t queryspeedup)
+{
+  if (ix == nullptr || (queryspeedup != 0 && queryspeedup != 2))
+  {
+    // the message of Vmengine/fquery.c:433-436 for values it does not know;
+    // 1 is refused by the reference's parser, 3..5 are undocumented variants
+    VSA_ERROR("illegal speedup value %lu", (unsigned long) queryspeedup);
+    return -1;
+  }
+  ix->qspeedup = queryspeedup;
   return 0;
 }
 

@@ -71,6 +71,9 @@ struct DevIndex
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars, D;
   uint32_t tune; // experiment switches (VSA_TUNE), see esa_search.hip
+  // Matchparam.queryspeedup (Vmengine/mparms.h:53): 0 or 2, decides the
+  // witness the MEM enumeration starts from
+  uint32_t qspeedup;
 };
 
 #define VSA_KEYSYMS 10u
@@ -94,6 +97,7 @@ struct vsa_index
   uint32_t *bck2;
   uint64_t *slot16;
   uint32_t D, tune;
+  uint32_t qspeedup; // vsa_index_set_queryspeedup: 0 or 2 (default)
   uint64_t querysepposition;
   int hasindexedqueries;
   uint64_t device_bytes;
@@ -117,6 +121,7 @@ struct vsa_index
     v.slot16 = slot16;
     v.D = D;
     v.tune = tune;
+    v.qspeedup = qspeedup;
     v.n = n;
     v.nllv = nllv;
     v.numofcodes = numofcodes;
