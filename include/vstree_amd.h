@@ -390,6 +390,20 @@ int vsa_findmaximaluniquematches(const vsa_index *index,
                                  uint64_t searchlength, vsa_result **result);
 
 /*
+  The same scan over a part of the suffix array: the values first <= i < last
+  of the reference's loop variable (fmumself.c:33 runs i = 2 .. totallength-1;
+  the bounds are clamped to that).  This is the multi-GPU form:
+  every rank holds the whole index, rank r of N scans
+  [2 + r*(n-2)/N, 2 + (r+1)*(n-2)/N) -- the entries i-2, i-1, i around the ends
+  of its range ("halo") come from its own copy of lcptab/bwttab -- and the
+  lists of the ranks, concatenated in rank order, are the list of the whole
+  scan; only the match counters are reduced.
+*/
+int vsa_findmaximaluniquematches_range(const vsa_index *index,
+                                       uint64_t searchlength, uint64_t first,
+                                       uint64_t last, vsa_result **result);
+
+/*
   mumuniqueinquery (kurtz/cleanMUMcand.c:55-118) on its own: MUM candidates
   resident in device memory (any order; e.g. gathered from several GPUs) ->
   MUMs in ascending dbstart order.  The candidate buffer is reordered.

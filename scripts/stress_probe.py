@@ -4,7 +4,9 @@ test suite: texts with planted repeats, low-complexity stretches, wildcards
 and several sequences; reads of mixed lengths with substitutions, indels,
 wildcards, duplicated and overlapping reads; random least lengths.  Every
 list (-complete, MEM, -mum cand, -mum) must equal the oracle's, order
-included (MEM: the order of -qspeedup 0).
+included (MEM: under -qspeedup 0 and under the default -qspeedup 2; every
+third round takes a small prefixlength and more low-complexity stretches so
+that buckets hold more than 255 suffixes and stitab1 saturates).
 usage: stress_probe.py [ROUNDS] [SEED]"""
 import os
 import sys
@@ -35,8 +37,8 @@ for rnd in range(rounds):
             for e in range(int(rng.integers(0, 4))):
                 u[int(rng.integers(0, ln))] = rng.integers(0, 4)
             t[b:b + ln] = u
-        for r in range(int(rng.integers(0, 4))):       # low complexity
-            ln = int(rng.integers(10, 300))
+        for r in range(int(rng.integers(0, 4 if rnd % 3 else 12))):
+            ln = int(rng.integers(10, 300 if rnd % 3 else 900))  # low complexity
             a = int(rng.integers(0, n - ln))
             unit = rng.integers(0, 4, int(rng.integers(1, 5)))
             t[a:a + ln] = np.resize(unit, ln)
@@ -45,10 +47,12 @@ for rnd in range(rounds):
         seqs.append(t)
     tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
                           for s in seqs])[:-1].astype(np.uint8)
-    gi = V.Index.build(tis, 4, 0)
+    gi = V.Index.build(tis, 4, 0 if rnd % 3 else int(rng.integers(1, 6)))
     tb = gi.download()
     host = H.Index(len(tis), gi.info().prefixlength, 4, tb["tis"], tb["suf"],
-                   tb["lcp"], tb["llv"], tb["bck"], tb["bwt"], None)
+                   tb["lcp"], tb["llv"], tb["bck"], tb["bwt"],
+                   H.sti1_from_tables(tb["suf"], tb["lcp"],
+                                      gi.info().prefixlength))
     reads = []
     uniform = rng.random() < 0.4
     m0 = int(rng.integers(30, 160))
@@ -79,13 +83,15 @@ for rnd in range(rounds):
     hq = H.Queries.from_list(reads)
     gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
     pl = gi.info().prefixlength
-    for L in sorted({pl, int(rng.integers(pl, 40)), 20}):
-        for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
-            got = V.findquerymatches(gi, gq, L, **kw).fetch()
-            want = H.oracle_querymatches(host, hq, L, speedup=0, **kw)
+    lo = max(pl, 6)     # below that every offset matches thousands of suffixes
+    for L in sorted({lo, int(rng.integers(lo, 40)), 20}):
+        for kw, sp in (({}, 0), ({}, 2), (dict(mum=True, cand=True), 2),
+                       (dict(mum=True), 0)):
+            got = V.findquerymatches(gi, gq, L, speedup=sp, **kw).fetch()
+            want = H.oracle_querymatches(host, hq, L, speedup=sp, **kw)
             if not np.array_equal(got, want):
-                print("MISMATCH round %d L %d %s: gpu %d oracle %d" % (
-                    rnd, L, kw, len(got), len(want)), flush=True)
+                print("MISMATCH round %d L %d %s sp %d: gpu %d oracle %d" % (
+                    rnd, L, kw, sp, len(got), len(want)), flush=True)
                 sys.exit(1)
             checked += 1
     if hq.length.min() >= pl:

@@ -325,6 +325,51 @@ def oracle_approx(index, queries, doedist, distvalue, percent=False):
     return res
 
 
+def selfmum_scan_range(index, searchlength, first=2, last=None):
+    """findmaximaluniquematches (Vmengine/fmumself.c:33-64) restated with numpy
+    for the values first <= i < last of its loop variable: what one rank of
+    the multi-GPU scan computes.  first=2, last=None is the whole loop."""
+    n = index.n
+    lcp = index.lcp.astype(np.int64)
+    if index.nllv:
+        llv = index.llv.reshape(-1, 2).astype(np.int64)
+        lcp[llv[:, 0]] = llv[:, 1]
+    first, last = max(2, int(first)), n if last is None else min(int(last), n)
+    i = np.arange(first, max(first, last), dtype=np.int64)
+    f, s, t = lcp[i - 2].copy(), lcp[i - 1], lcp[i]
+    f[i == 2] = 0                        # firstlcp starts at 0
+    ok = (s >= searchlength) & (f < s) & (t < s)
+    i, s = i[ok], s[ok]
+    a, b = index.suf[i - 2].astype(np.int64), index.suf[i - 1].astype(np.int64)
+    s1, s2 = np.minimum(a, b), np.maximum(a, b)
+    sep = index.querysepposition
+    x, y = index.bwt[i - 1], index.bwt[i - 2]
+    ok = (s1 < sep) & (s2 > sep) & ((s1 == 0) | (x >= WILDCARD) |
+                                    (y >= WILDCARD) | (x != y))
+    out = np.zeros(int(ok.sum()), MATCH_DTYPE)
+    out["length"], out["dbstart"], out["queryseq"] = s[ok], s1[ok], s2[ok]
+    return out
+
+
+def sti1_from_tables(suf, lcp, prefixlength, chunk=1 << 26):
+    """Table stitab1 from its definition (Mkvtree/mkvprocess.c:583-612):
+    sti1[suf[i]] = min(255, i - start of i's run of lcp >= prefixlength);
+    numpy, in chunks, for tables of any size."""
+    n1 = len(suf)
+    out = np.zeros(n1, np.uint8)
+    carry = 0                               # start of the run reaching in
+    for a in range(0, n1, chunk):
+        b = min(n1, a + chunk)
+        idx = np.arange(a, b, dtype=np.int64)
+        starts = np.where(lcp[a:b] < prefixlength, idx, -1)
+        if a == 0:
+            starts[0] = 0
+        runstart = np.maximum.accumulate(np.maximum(starts, carry))
+        carry = int(runstart[-1])
+        out[suf[a:b]] = np.minimum(idx - runstart, 255).astype(np.uint8)
+    return out
+
+
 def oracle_querymatches(index, queries, searchlength, mum=False, cand=False,
                         speedup=0):
     lib = oracle_lib()

@@ -106,9 +106,8 @@ def test_sample_parity_with_cpu_oracle_on_full_index(V, world):
     assert np.array_equal(V.findcompletematches(ix, gq).fetch(),
                           H.oracle_complete(host, hq))
     if host.sti1 is None:
-        # the reference's default algorithm 2 reads stitab1; the table the GPU
-        # derives is checked against mkvtree's own in tests/test_gpu_mkvtree.py
-        host.sti1 = ix.make_sti1()
+        # the reference's default algorithm 2 reads stitab1
+        host.sti1 = H.sti1_from_tables(host.suf, host.lcp, host.prefixlength)
     for kw, sp in (({}, 0), ({}, 2), (dict(mum=True, cand=True), 2),
                    (dict(mum=True), 2)):
         assert np.array_equal(

@@ -196,6 +196,57 @@ def test_index_open_reads_mkvtree_files(V, tmp_path):
     assert np.array_equal(got, H.expected("grumbach_all", "selfmum14"))
 
 
+def test_self_index_scan_by_ranges(V):
+    """vsa_findmaximaluniquematches_range (third row): any tiling
+    of the reference's loop i = 2 .. n-1 (fmumself.c:33) into ranges gives,
+    range by range, the matches of that part of the loop, and concatenated
+    the list of the whole scan -- cuts at tile boundaries, next to peaks, empty
+    and clamped ranges included"""
+    from vstree_amd import sharding as S
+    rng = np.random.default_rng(99)
+    db = rng.integers(0, 4, 150000).astype(np.uint8)
+    qy = db[20000:120000].copy()
+    qy[rng.random(len(qy)) < 0.01] = rng.integers(0, 4)     # diverged copy
+    db[1000:1400] = db[5000:5400]                           # lcp >= 255 inside
+    qy[300:700] = db[1000:1400]
+    tis = np.concatenate([db, [H.SEPARATOR], qy]).astype(np.uint8)
+    synth = H.oracle_build_index(tis, 4)
+    synth.querysepposition, synth.hasqueries = len(db), True
+    gsynth = V.Index.from_tables(synth.n, synth.prefixlength, 4, synth.tis,
+                                 synth.suf, synth.lcp, synth.llv, synth.bck,
+                                 synth.bwt, len(db), True)
+    real, _ = H.load_case("grumbach_all")
+    for idx, gi, L in ((real, gpu_index(V, "grumbach_all"), 14),
+                       (synth, gsynth, 12), (synth, gsynth, 300)):
+        whole = V.findmaximaluniquematches(gi, L).fetch()
+        assert np.array_equal(whole, H.oracle_selfmum(idx, L))
+        assert len(whole) > (50 if L < 255 else 0)
+        n = idx.n
+        peaks = np.flatnonzero(idx.lcp[:n] >= min(L, 255))
+        tilings = [[S.selfmum_range(n, r, w) for r in range(w)]
+                   for w in (1, 2, 3, 8)]
+        cuts = sorted({2, n} | {int(c) for c in rng.integers(2, n, 6)} |
+                      {4096, 4097, 8191, 16384, 16385} |
+                      {int(p) + d for p in peaks[:3] for d in (0, 1, 2)})
+        tilings.append(list(zip(cuts, cuts[1:])))
+        for tiling in tilings:
+            parts = []
+            for first, last in tiling:
+                got = V.findmaximaluniquematches(gi, L, first, last).fetch()
+                assert np.array_equal(
+                    got, H.selfmum_scan_range(idx, L, first, last)), (
+                        L, first, last)
+                parts.append(got)
+            assert np.array_equal(np.concatenate(parts), whole), (L, tiling)
+        # clamped and empty ranges
+        assert np.array_equal(
+            V.findmaximaluniquematches(gi, L, 0, 2 ** 63).fetch(), whole)
+        assert len(V.findmaximaluniquematches(gi, L, 500, 500).fetch()) == 0
+        assert len(V.findmaximaluniquematches(gi, L, n, n + 9).fetch()) == 0
+    with pytest.raises(V.VsaError):
+        V.findmaximaluniquematches(gsynth, 12, 10, 5)
+
+
 def test_random_ragged_queries_with_wildcards(V):
     """seeded random index with separators and wildcards, ragged queries"""
     rng = np.random.default_rng(777)

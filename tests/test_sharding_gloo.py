@@ -134,6 +134,63 @@ def test_two_ranks_reproduce_the_single_process_reference(tmp_path):
                                       int(want_c["length"].sum())]
 
 
+def _selfmum_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (H.ROOT, os.path.join(H.ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from vstree_amd import sharding as S
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx, _ = H.load_case("grumbach_all")
+    first, last = S.selfmum_range(idx.n, rank, world)
+    mine = H.selfmum_scan_range(idx, 14, first, last)
+    totals = S.all_reduce_counters(dist, torch,
+                                   [len(mine), int(mine["length"].sum())],
+                                   "cpu")
+    parts, _ = S.all_gather_matches(dist, torch,
+                                    S.matches_to_tensor(torch, mine), "cpu")
+    if rank == 0:
+        np.savez(os.path.join(outdir, "selfmum.npz"),
+                 mums=S.tensor_to_matches(torch.cat(parts), H.MATCH_DTYPE),
+                 totals=np.array(totals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_self_index_scan_split_over_two_ranks(tmp_path):
+    """SURVEY 8e, third row: the scan of fmumself.c split into suffix-array
+    ranges, one per rank; rank order = suffix-array order = reference order;
+    only the counters are reduced."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    idx, _ = H.load_case("grumbach_all")
+    mp.spawn(_selfmum_worker, args=(WORLD, port, str(tmp_path)),
+             nprocs=WORLD, join=True)
+    out = np.load(os.path.join(str(tmp_path), "selfmum.npz"))
+    want = H.expected("grumbach_all", "selfmum14")
+    assert np.array_equal(H.selfmatches_as_ref(idx, out["mums"]), want)
+    assert out["totals"].tolist() == [len(want), int(want["length"].sum())]
+    # the range restatement is the oracle's scan when it covers everything
+    assert np.array_equal(H.selfmum_scan_range(idx, 14),
+                          H.oracle_selfmum(idx, 14))
+
+
+def test_selfmum_ranges_tile_the_scan():
+    from vstree_amd import sharding as S
+    for n in (2, 3, 4, 10, 1000003):
+        for world in (1, 2, 3, 8):
+            r = [S.selfmum_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 2 and r[-1][1] == max(n, 2)
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
 def test_shard_range_covers_everything():
     from vstree_amd import sharding as S
     for total in (0, 1, 7, 10, 1000003):

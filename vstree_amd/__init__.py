@@ -142,6 +142,7 @@ def _load():
         "vsa_findmumcandidates": (I, [V, V, U64, I, PP]),
         "vsa_result_partition": (I, [V, U32, U64, V, V, V]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
+        "vsa_findmaximaluniquematches_range": (I, [V, U64, U64, U64, PP]),
         "vsa_findmaximalrepeats": (I, [V, U64, PP]),
         "vsa_findmaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findsupermaximalrepeats": (I, [V, U64, PP]),
@@ -475,11 +476,17 @@ def findtandems(index, searchlength):
     return Result(h)
 
 
-def findmaximaluniquematches(index, searchlength):
-    """vmatch -mum -l L IDX (Vmengine/fmumself.c:10)."""
+def findmaximaluniquematches(index, searchlength, first=None, last=None):
+    """vmatch -mum -l L IDX (Vmengine/fmumself.c:10); first/last: the part
+    first <= i < last of the reference's scan (multi-GPU form)."""
     h = C.c_void_p()
-    _check(lib.vsa_findmaximaluniquematches(index._h, int(searchlength),
-                                            C.byref(h)))
+    if first is None and last is None:
+        _check(lib.vsa_findmaximaluniquematches(index._h, int(searchlength),
+                                                C.byref(h)))
+    else:
+        _check(lib.vsa_findmaximaluniquematches_range(
+            index._h, int(searchlength), int(first or 0),
+            int(last if last is not None else 2 ** 64 - 1), C.byref(h)))
     return Result(h)
 
 

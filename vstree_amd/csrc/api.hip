@@ -47,7 +47,7 @@ extern "C" int vsa_device_malloc(uint64_t bytes, int device, void **ptr)
   {
     return -100;
   }
-  VSA_HIP(hipMalloc(ptr, bytes > 0 ? bytes : 16));
+  VSA_HIP(vsa_hip_malloc(ptr, bytes > 0 ? bytes : 16));
   return 0;
 }
 
@@ -190,15 +190,15 @@ int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
                  sufbytes = (n + 1) * ix->isize, lcpbytes = n + 1 + 32,
                  llvbytes = 2 * nllv * ix->isize + 16,
                  bckbytes = 2 * ix->numofcodes * ix->isize;
-  VSA_HIP(hipMalloc((void **) &ix->tis_alloc, tisbytes));
-  VSA_HIP(hipMalloc(&ix->suf, sufbytes));
-  VSA_HIP(hipMalloc((void **) &ix->lcp, lcpbytes));
-  VSA_HIP(hipMalloc(&ix->llv, llvbytes));
-  VSA_HIP(hipMalloc(&ix->bck, bckbytes));
+  VSA_HIP(vsa_hip_malloc((void **) &ix->tis_alloc, tisbytes));
+  VSA_HIP(vsa_hip_malloc(&ix->suf, sufbytes));
+  VSA_HIP(vsa_hip_malloc((void **) &ix->lcp, lcpbytes));
+  VSA_HIP(vsa_hip_malloc(&ix->llv, llvbytes));
+  VSA_HIP(vsa_hip_malloc(&ix->bck, bckbytes));
   ix->device_bytes = tisbytes + sufbytes + lcpbytes + llvbytes + bckbytes;
   if (withbwt)
   {
-    VSA_HIP(hipMalloc((void **) &ix->bwt, n + 1 + 32));
+    VSA_HIP(vsa_hip_malloc((void **) &ix->bwt, n + 1 + 32));
     ix->device_bytes += n + 1 + 32;
   }
   // pads: separator symbols around the text, zeros behind lcp
@@ -228,6 +228,7 @@ extern "C" void vsa_index_close(vsa_index *ix)
   (void) hipFree(ix->slot16);
   if (ix->stream != nullptr)
   {
+    vsa_dev_forget_stream(ix->stream);
     (void) hipStreamDestroy(ix->stream);
   }
   delete ix;
@@ -475,6 +476,22 @@ void summarise_lengths(vsa_queries *q)
 
 } // namespace
 
+// a HIP call inside a constructor of a query batch: on failure the half-built
+// object is released and the out-parameter cleared before the error returns
+#define VSA_HIPQ(obj, out, call)                                              \
+  do                                                                          \
+  {                                                                           \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess)                                                     \
+    {                                                                         \
+      VSA_ERROR("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,            \
+                hipGetErrorString(e_));                                       \
+      vsa_queries_free(obj);                                                  \
+      *(out) = nullptr;                                                       \
+      return -100;                                                            \
+    }                                                                         \
+  } while (0)
+
 extern "C" int vsa_queries_from_host(const uint8_t *symbols,
                                      uint64_t nsymbols, const uint64_t *start,
                                      const uint64_t *length, uint64_t nq,
@@ -518,18 +535,18 @@ extern "C" int vsa_queries_from_host(const uint8_t *symbols,
     q->dense = start[i] == i * length[0];
   }
   *queries = q;
-  VSA_HIP(hipMalloc((void **) &q->symbols, nsymbols + VSA_QUERY_BACKPAD));
-  VSA_HIP(hipMalloc((void **) &q->start, (nq + 1) * 8));
-  VSA_HIP(hipMalloc((void **) &q->length, (nq + 1) * 8));
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->symbols, nsymbols + VSA_QUERY_BACKPAD));
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->start, (nq + 1) * 8));
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->length, (nq + 1) * 8));
   if (nsymbols > 0)
   {
-    VSA_HIP(hipMemcpy(q->symbols, symbols, nsymbols, hipMemcpyHostToDevice));
+    VSA_HIPQ(q, queries, hipMemcpy(q->symbols, symbols, nsymbols, hipMemcpyHostToDevice));
   }
-  VSA_HIP(hipMemset(q->symbols + nsymbols, 0xFF, VSA_QUERY_BACKPAD));
+  VSA_HIPQ(q, queries, hipMemset(q->symbols + nsymbols, 0xFF, VSA_QUERY_BACKPAD));
   if (nq > 0)
   {
-    VSA_HIP(hipMemcpy(q->start, start, nq * 8, hipMemcpyHostToDevice));
-    VSA_HIP(hipMemcpy(q->length, length, nq * 8, hipMemcpyHostToDevice));
+    VSA_HIPQ(q, queries, hipMemcpy(q->start, start, nq * 8, hipMemcpyHostToDevice));
+    VSA_HIPQ(q, queries, hipMemcpy(q->length, length, nq * 8, hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -570,22 +587,22 @@ extern "C" int vsa_queries_from_device(const void *device_symbols,
   summarise_lengths(q);
   q->dense = q->uniform;
   *queries = q;
-  VSA_HIP(hipMalloc((void **) &q->symbols,
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->symbols,
                     q->nsymbols + VSA_QUERY_BACKPAD));
-  VSA_HIP(hipMalloc((void **) &q->start, (nq + 1) * 8));
-  VSA_HIP(hipMalloc((void **) &q->length, (nq + 1) * 8));
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->start, (nq + 1) * 8));
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->length, (nq + 1) * 8));
   if (q->nsymbols > 0)
   {
-    VSA_HIP(hipMemcpy(q->symbols, device_symbols, q->nsymbols,
+    VSA_HIPQ(q, queries, hipMemcpy(q->symbols, device_symbols, q->nsymbols,
                       hipMemcpyDeviceToDevice));
   }
-  VSA_HIP(hipMemset(q->symbols + q->nsymbols, 0xFF, VSA_QUERY_BACKPAD));
+  VSA_HIPQ(q, queries, hipMemset(q->symbols + q->nsymbols, 0xFF, VSA_QUERY_BACKPAD));
   if (nq > 0)
   {
     k_uniform_starts<<<(unsigned int) ((nq + 255) / 256), 256>>>(
         q->start, q->length, nq, m);
-    VSA_HIP(hipGetLastError());
-    VSA_HIP(hipDeviceSynchronize());
+    VSA_HIPQ(q, queries, hipGetLastError());
+    VSA_HIPQ(q, queries, hipDeviceSynchronize());
   }
   return 0;
 }
@@ -652,26 +669,26 @@ extern "C" int vsa_queries_reverse_complement(const vsa_queries *q,
   r->dense = q->dense;
   *rcqueries = r;
   uint32_t *dbad = nullptr, hbad = 0;
-  VSA_HIP(hipMalloc((void **) &r->symbols, r->nsymbols + VSA_QUERY_BACKPAD));
-  VSA_HIP(hipMalloc((void **) &r->start, (r->nq + 1) * 8));
-  VSA_HIP(hipMalloc((void **) &r->length, (r->nq + 1) * 8));
-  VSA_HIP(hipMalloc((void **) &dbad, 4));
-  VSA_HIP(hipMemset(dbad, 0, 4));
+  VSA_HIPQ(r, rcqueries, vsa_hip_malloc((void **) &r->symbols, r->nsymbols + VSA_QUERY_BACKPAD));
+  VSA_HIPQ(r, rcqueries, vsa_hip_malloc((void **) &r->start, (r->nq + 1) * 8));
+  VSA_HIPQ(r, rcqueries, vsa_hip_malloc((void **) &r->length, (r->nq + 1) * 8));
+  VSA_HIPQ(r, rcqueries, vsa_hip_malloc((void **) &dbad, 4));
+  VSA_HIPQ(r, rcqueries, hipMemset(dbad, 0, 4));
   // separators between the sequences and the padding stay what they are
-  VSA_HIP(hipMemcpy(r->symbols, q->symbols,
+  VSA_HIPQ(r, rcqueries, hipMemcpy(r->symbols, q->symbols,
                     r->nsymbols + VSA_QUERY_BACKPAD,
                     hipMemcpyDeviceToDevice));
-  VSA_HIP(hipMemcpy(r->start, q->start, (r->nq + 1) * 8,
+  VSA_HIPQ(r, rcqueries, hipMemcpy(r->start, q->start, (r->nq + 1) * 8,
                     hipMemcpyDeviceToDevice));
-  VSA_HIP(hipMemcpy(r->length, q->length, (r->nq + 1) * 8,
+  VSA_HIPQ(r, rcqueries, hipMemcpy(r->length, q->length, (r->nq + 1) * 8,
                     hipMemcpyDeviceToDevice));
   if (r->nq > 0)
   {
     k_reverse_complement<<<(unsigned int) ((r->nq * 64 + 255) / 256), 256>>>(
         q->symbols, q->start, q->length, r->nq, r->symbols, dbad);
-    VSA_HIP(hipGetLastError());
+    VSA_HIPQ(r, rcqueries, hipGetLastError());
   }
-  VSA_HIP(hipMemcpy(&hbad, dbad, 4, hipMemcpyDeviceToHost));
+  VSA_HIPQ(r, rcqueries, hipMemcpy(&hbad, dbad, 4, hipMemcpyDeviceToHost));
   (void) hipFree(dbad);
   if (hbad != 0)
   {
@@ -736,6 +753,7 @@ extern "C" int vsa_result_fetch(const vsa_result *r, vsa_match *matches,
   {
     // pairs: as records through a temporary
     void *tmp = nullptr;
+    vsa_dev_set_stream(nullptr); // vsa_unpack_result: default stream
     if (vsa_dev_alloc(&tmp, m * sizeof(vsa_match)) != 0)
     {
       return -100;
@@ -873,8 +891,8 @@ extern "C" int vsa_measure_random_read(uint64_t bytes, int inflight,
   unsigned long long *sink = nullptr;
   const uint64_t nwords = bytes / 8, threads = 256ull * 256 * 32,
                  perthread = 64;
-  VSA_HIP(hipMalloc(&buf, nwords * 8 + 16));
-  VSA_HIP(hipMalloc((void **) &sink, 8));
+  VSA_HIP(vsa_hip_malloc(&buf, nwords * 8 + 16));
+  VSA_HIP(vsa_hip_malloc((void **) &sink, 8));
   VSA_HIP(hipMemset(buf, 1, nwords * 8));
   VSA_HIP(hipMemset(sink, 0, 8));
   hipEvent_t a, b;
@@ -923,8 +941,8 @@ extern "C" int vsa_measure_stream_read(uint64_t bytes, int device,
   void *buf = nullptr;
   unsigned long long *sink = nullptr;
   const uint64_t n16 = bytes / 16;
-  VSA_HIP(hipMalloc(&buf, n16 * 16 + 16));
-  VSA_HIP(hipMalloc((void **) &sink, 8));
+  VSA_HIP(vsa_hip_malloc(&buf, n16 * 16 + 16));
+  VSA_HIP(vsa_hip_malloc((void **) &sink, 8));
   VSA_HIP(hipMemset(buf, 1, n16 * 16));
   VSA_HIP(hipMemset(sink, 0, 8));
   hipEvent_t a, b;

@@ -18,16 +18,33 @@ namespace
 const size_t kMaxCachedBlock = 8ull << 30;  // do not keep blocks above 8 GiB
 const size_t kMaxCachedTotal = 48ull << 30; // per process
 
+// Reuse is stream ordered.  A block remembers the stream its user works on
+// (vsa_dev_set_stream, set by every pipeline entry for the calling thread).
+// Freeing it records an event on that stream; handing it to a user on the
+// same stream needs nothing (the new work is queued behind the old), handing
+// it to another stream makes that stream wait for the event.  So a DevBuf
+// destructor may run while kernels that touch the block are still queued --
+// the early exits of the pipelines (VSA_HIP returns) do exactly that.
 struct Block
 {
   size_t cls;
   int device;
+  hipStream_t stream;
+};
+
+struct Cached
+{
+  void *ptr;
+  hipStream_t stream;
+  hipEvent_t done; // nullptr: nothing pending (the device was synchronised)
 };
 
 std::mutex g_lock;
 std::unordered_map<void *, Block> g_live;                   // handed out
-std::map<std::pair<int, size_t>, std::vector<void *>> g_free; // cached
+std::map<std::pair<int, size_t>, std::vector<Cached>> g_free; // cached
+std::vector<hipEvent_t> g_events;                           // spare events
 size_t g_cached = 0;
+thread_local hipStream_t t_stream = nullptr;
 
 size_t sizeclass(size_t bytes)
 {
@@ -56,20 +73,76 @@ size_t sizeclass(size_t bytes)
 
 } // namespace
 
+void vsa_dev_set_stream(hipStream_t stream)
+{
+  t_stream = stream;
+}
+
+// the stream is about to be destroyed (vsa_index_close): finish its work and
+// detach every block from it
+void vsa_dev_forget_stream(hipStream_t stream)
+{
+  if (stream == nullptr)
+  {
+    return;
+  }
+  (void) hipStreamSynchronize(stream);
+  if (t_stream == stream)
+  {
+    t_stream = nullptr;
+  }
+  std::lock_guard<std::mutex> g(g_lock);
+  for (auto &kv : g_live)
+  {
+    if (kv.second.stream == stream)
+    {
+      kv.second.stream = nullptr;
+    }
+  }
+  for (auto &kv : g_free)
+  {
+    for (Cached &c : kv.second)
+    {
+      if (c.stream == stream)
+      {
+        c.stream = nullptr;
+        if (c.done != nullptr)
+        {
+          g_events.push_back(c.done); // recorded on that stream: over
+          c.done = nullptr;
+        }
+      }
+    }
+  }
+}
+
 int vsa_dev_alloc(void **ptr, size_t bytes)
 {
   int device = 0;
   VSA_HIP(hipGetDevice(&device));
   const size_t cls = sizeclass(bytes);
   {
-    std::lock_guard<std::mutex> g(g_lock);
+    std::unique_lock<std::mutex> g(g_lock);
     auto it = g_free.find(std::make_pair(device, cls));
     if (it != g_free.end() && !it->second.empty())
     {
-      *ptr = it->second.back();
+      const Cached c = it->second.back();
       it->second.pop_back();
       g_cached -= cls;
-      g_live[*ptr] = Block{cls, device};
+      g_live[c.ptr] = Block{cls, device, t_stream};
+      g.unlock();
+      *ptr = c.ptr;
+      if (c.done != nullptr)
+      {
+        if (c.stream != t_stream &&
+            hipStreamWaitEvent(t_stream, c.done, 0) != hipSuccess)
+        {
+          (void) hipGetLastError();
+          (void) hipEventSynchronize(c.done);
+        }
+        std::lock_guard<std::mutex> g2(g_lock);
+        g_events.push_back(c.done); // the wait holds its own reference
+      }
       return 0;
     }
   }
@@ -77,6 +150,7 @@ int vsa_dev_alloc(void **ptr, size_t bytes)
   if (e != hipSuccess)
   {
     // give cached memory back and try once more
+    (void) hipGetLastError();
     vsa_dev_trim();
     e = hipMalloc(ptr, cls);
   }
@@ -88,8 +162,22 @@ int vsa_dev_alloc(void **ptr, size_t bytes)
     return -100;
   }
   std::lock_guard<std::mutex> g(g_lock);
-  g_live[*ptr] = Block{cls, device};
+  g_live[*ptr] = Block{cls, device, t_stream};
   return 0;
+}
+
+// Long-lived tables (index, query batches): plain hipMalloc, but memory the
+// cache holds is given back before an allocation is declared impossible.
+hipError_t vsa_hip_malloc(void **ptr, size_t bytes)
+{
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e == hipErrorOutOfMemory)
+  {
+    (void) hipGetLastError();
+    vsa_dev_trim();
+    e = hipMalloc(ptr, bytes);
+  }
+  return e;
 }
 
 void vsa_dev_free(void *ptr)
@@ -99,6 +187,7 @@ void vsa_dev_free(void *ptr)
     return;
   }
   Block b;
+  hipEvent_t ev = nullptr;
   {
     std::lock_guard<std::mutex> g(g_lock);
     auto it = g_live.find(ptr);
@@ -110,34 +199,72 @@ void vsa_dev_free(void *ptr)
     }
     b = it->second;
     g_live.erase(it);
-    if (b.cls <= kMaxCachedBlock && g_cached + b.cls <= kMaxCachedTotal)
+    if (b.cls > kMaxCachedBlock || g_cached + b.cls > kMaxCachedTotal)
     {
-      g_free[std::make_pair(b.device, b.cls)].push_back(ptr);
-      g_cached += b.cls;
+      (void) hipFree(ptr); // synchronises the device
       return;
     }
+    if (!g_events.empty())
+    {
+      ev = g_events.back();
+      g_events.pop_back();
+    }
   }
-  (void) hipFree(ptr);
+  // what is queued on the block's stream right now may still use it
+  int current = 0;
+  const bool switched = hipGetDevice(&current) == hipSuccess &&
+                        current != b.device &&
+                        hipSetDevice(b.device) == hipSuccess;
+  if (ev == nullptr &&
+      hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+  {
+    ev = nullptr;
+  }
+  if (ev == nullptr || hipEventRecord(ev, b.stream) != hipSuccess)
+  {
+    // no event to be had, or the stream is gone (index closed before its
+    // result lists): wait for the device instead
+    (void) hipGetLastError();
+    (void) hipDeviceSynchronize();
+    if (ev != nullptr)
+    {
+      std::lock_guard<std::mutex> g(g_lock);
+      g_events.push_back(ev);
+      ev = nullptr;
+    }
+  }
+  if (switched)
+  {
+    (void) hipSetDevice(current);
+  }
+  std::lock_guard<std::mutex> g(g_lock);
+  g_free[std::make_pair(b.device, b.cls)].push_back(Cached{ptr, b.stream, ev});
+  g_cached += b.cls;
 }
 
 void vsa_dev_trim()
 {
-  std::vector<void *> all;
+  std::vector<Cached> all;
   {
     std::lock_guard<std::mutex> g(g_lock);
     for (auto &kv : g_free)
     {
-      for (void *p : kv.second)
+      for (const Cached &c : kv.second)
       {
-        all.push_back(p);
+        all.push_back(c);
       }
       kv.second.clear();
     }
     g_cached = 0;
   }
-  for (void *p : all)
+  for (const Cached &c : all)
   {
-    (void) hipFree(p);
+    (void) hipFree(c.ptr); // synchronises: pending work is over afterwards
+    if (c.done != nullptr)
+    {
+      std::lock_guard<std::mutex> g(g_lock);
+      g_events.push_back(c.done);
+    }
   }
 }
 

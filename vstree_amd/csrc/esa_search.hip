@@ -388,6 +388,7 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
                  uint64_t qlimit, vsa_result *res)
 {
   hipStream_t stream = index->stream;
+  vsa_dev_set_stream(stream);
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
   const DevQueries qs = devqueries(queries);
@@ -867,6 +868,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // forcebits != 0 (with domumcand, !ordered): the candidates stay pairs with
   // this many length bits (vsa_findmumcandidates_packed)
   hipStream_t stream = index->stream;
+  vsa_dev_set_stream(stream);
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
   const DevQueries qs = devqueries(queries);
@@ -1427,29 +1429,40 @@ static uint64_t vsa_peakblocks(void)
   return v > 0 ? (uint64_t) v : 1024;
 }
 
+// [first, last) = the values of the reference's loop variable i
+// (fmumself.c:33: i = 2 .. n-1) this call covers
 template <typename IDX>
 int run_selfmum(const vsa_index *index, uint64_t searchlength,
-                vsa_result *res)
+                uint64_t first, uint64_t last, vsa_result *res)
 {
   hipStream_t stream = index->stream;
+  vsa_dev_set_stream(stream);
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
   const uint64_t n = index->n;
   const uint32_t nshards = VSA_CURSOR_SHARDS;
   const int variant = vsa_peakvariant();
   const uint64_t pieces = (variant & 2) ? 2 : 4, tilesize = 64 * pieces * 16;
-  const uint64_t ntiles = (n + 1 + tilesize - 1) / tilesize,
+  // centres j = i - 1
+  const uint64_t jlo = std::max<uint64_t>(first, 2) - 1,
+                 jhi = std::max<uint64_t>(std::min<uint64_t>(last, n), 2) - 1;
+  const uint64_t tile0 = jlo / tilesize,
+                 ntiles = jhi > jlo ? (jhi + tilesize - 1) / tilesize : tile0,
                  wavesperblock = VSA_BLOCK / 64;
-  const uint64_t nblocks =
-      std::min<uint64_t>((ntiles + wavesperblock - 1) / wavesperblock,
-                         (uint64_t) vsa_peakblocks());
+  const uint64_t nblocks = std::max<uint64_t>(
+      1, std::min<uint64_t>((ntiles - tile0 + wavesperblock - 1) /
+                                wavesperblock,
+                            (uint64_t) vsa_peakblocks()));
   const uint32_t slmin = (uint32_t) (searchlength < 255 ? searchlength : 255);
   DevBuf cursor, doff, rawpos, peaks, sorted, temp, cand, keep, dcount, mums;
-  uint64_t shardcap = std::max<uint64_t>(n / 64 / nshards + 1024, 4096),
+  uint64_t shardcap =
+               std::max<uint64_t>((jhi - std::min(jlo, jhi)) / 64 / nshards +
+                                      1024,
+                                  4096),
            needed = 0, maxshard = 0;
   double searchms = 0;
 
-  res->stats.searches = n;
+  res->stats.searches = jhi > jlo ? jhi - jlo : 0;
   if (n + 1 >= 0xFFFFFFFFull)
   {
     VSA_ERROR("self-index MUM scan: texts beyond 2^32 are not supported");
@@ -1475,7 +1488,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   k_selfmum_peaks<PIECES, NT><<<(unsigned int) nblocks, VSA_BLOCK, 0,         \
                                 stream>>>(                                    \
       ix.lcp, ix.bwt, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1, \
-      cursor.as<unsigned long long>(), ntiles)
+      cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi)
     switch (variant)
     {
       case 1: VSA_PEAKS(4, true); break;
@@ -1671,8 +1684,8 @@ int vsa_index_make_esa8(vsa_index *ix)
   const char *tune = getenv("VSA_TUNE");
   ix->tune = tune != nullptr ? (uint32_t) atoi(tune) : 0;
   const uint64_t count = ix->n + 1, ncodes = 1ull << (2 * D);
-  VSA_HIP(hipMalloc((void **) &ix->bck2, 2 * ncodes * 4 + 16));
-  VSA_HIP(hipMalloc((void **) &ix->esa8, count * 8 + 64));
+  VSA_HIP(vsa_hip_malloc((void **) &ix->bck2, 2 * ncodes * 4 + 16));
+  VSA_HIP(vsa_hip_malloc((void **) &ix->esa8, count * 8 + 64));
   ix->device_bytes += count * 8 + 2 * ncodes * 4;
   if (vsa_build_bucket_table(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
                              (const uint32_t *) ix->suf, D, 4, ix->bck2,
@@ -1690,7 +1703,7 @@ int vsa_index_make_esa8(vsa_index *ix)
   const char *noslot = getenv("VSA_SLOT16");
   if (!(noslot != nullptr && strcmp(noslot, "0") == 0))
   {
-    VSA_HIP(hipMalloc((void **) &ix->slot16, 2 * ncodes * 8 + 16));
+    VSA_HIP(vsa_hip_malloc((void **) &ix->slot16, 2 * ncodes * 8 + 16));
     k_make_slot16<<<(unsigned int) std::min<uint64_t>(
                         (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20),
                     VSA_BLOCK, 0, ix->stream>>>(ix->bck2, ix->esa8, ncodes,
@@ -2050,6 +2063,7 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
     return -100;
   }
   hipStream_t stream = nullptr;
+  vsa_dev_set_stream(stream);
   const uint64_t nblocks = gridfor(n), cells = (uint64_t) nparts * nblocks;
   DevBuf hist, top, offsets, summary, temp;
   uint64_t host[2 * VSA_PART_MAX + 1];
@@ -2237,6 +2251,7 @@ static int mumfilter_entry(void *device_candidates, uint64_t ncandidates,
   }
   vsa_result *res = newresult(device);
   hipStream_t stream = nullptr; // default stream: no index handle here
+  vsa_dev_set_stream(stream);
   Timer tall(stream);
   DevBuf cand, mums;
   cand.p = device_candidates; // borrowed, released below
@@ -2346,6 +2361,7 @@ extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
   }
   vsa_result *res = newresult(device);
   hipStream_t stream = nullptr; // default stream: no index handle here
+  vsa_dev_set_stream(stream);
   Timer tall(stream);
   DevBuf keys, vals, mums;
   uint64_t nm = 0, sum = 0;
@@ -2522,13 +2538,20 @@ extern "C" int vsa_findtandems(const vsa_index *index, uint64_t searchlength,
   return 0;
 }
 
-extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,
-                                            uint64_t searchlength,
-                                            vsa_result **result)
+extern "C" int vsa_findmaximaluniquematches_range(const vsa_index *index,
+                                                  uint64_t searchlength,
+                                                  uint64_t first,
+                                                  uint64_t last,
+                                                  vsa_result **result)
 {
   if (index == nullptr || result == nullptr)
   {
     VSA_ERROR("vsa_findmaximaluniquematches: NULL argument");
+    return -1;
+  }
+  if (first > last)
+  {
+    VSA_ERROR("vsa_findmaximaluniquematches_range: first > last");
     return -1;
   }
   *result = nullptr;
@@ -2556,8 +2579,10 @@ extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,
   }
   vsa_result *res = newresult(index->device);
   const int rc = (index->isize == 4)
-                     ? run_selfmum<uint32_t>(index, searchlength, res)
-                     : run_selfmum<uint64_t>(index, searchlength, res);
+                     ? run_selfmum<uint32_t>(index, searchlength, first, last,
+                                             res)
+                     : run_selfmum<uint64_t>(index, searchlength, first, last,
+                                             res);
   if (rc != 0)
   {
     vsa_result_free(res);
@@ -2565,4 +2590,12 @@ extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,
   }
   *result = res;
   return 0;
+}
+
+extern "C" int vsa_findmaximaluniquematches(const vsa_index *index,
+                                            uint64_t searchlength,
+                                            vsa_result **result)
+{
+  return vsa_findmaximaluniquematches_range(index, searchlength, 2, ~0ull,
+                                            result);
 }

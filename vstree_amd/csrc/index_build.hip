@@ -467,6 +467,7 @@ int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
                            hipStream_t stream)
 {
   DevBuf left, mid, temp;
+  vsa_dev_set_stream(stream);
   uint64_t nc = 1;
   for (uint32_t k = 0; k < pl; k++)
   {
@@ -510,6 +511,7 @@ namespace
 int build_tables(vsa_index *ix)
 {
   hipStream_t stream = ix->stream;
+  vsa_dev_set_stream(stream);
   const uint64_t n = ix->n, count = n + 1;
   const uint8_t *tis = ix->tis_alloc + VSA_TIS_FRONTPAD;
   uint32_t *sa = (uint32_t *) ix->suf;
@@ -704,7 +706,7 @@ int build_tables(vsa_index *ix)
     ix->nllv = needed;
     (void) hipFree(ix->llv);
     ix->llv = nullptr;
-    VSA_HIP(hipMalloc(&ix->llv, 2 * needed * 4 + 16));
+    VSA_HIP(vsa_hip_malloc(&ix->llv, 2 * needed * 4 + 16));
     ix->device_bytes += 2 * needed * 4;
     if (needed > 0)
     {
@@ -863,6 +865,7 @@ extern "C" int vsa_index_make_sti1(const vsa_index *ix, uint8_t *sti1)
   }
   const uint64_t count = ix->n + 1;
   DevBuf runstart, out;
+  vsa_dev_set_stream(ix->stream);
   if (runstart.alloc(count * 4) || out.alloc(count))
   {
     return -100;

@@ -196,6 +196,13 @@ int vsa_set_device(int device);
 int vsa_dev_alloc(void **ptr, size_t bytes);
 void vsa_dev_free(void *ptr);
 void vsa_dev_trim();
+// the stream the calling thread's pipeline runs on: blocks are handed out and
+// taken back in the order of that stream (see devmem.hip)
+void vsa_dev_set_stream(hipStream_t stream);
+void vsa_dev_forget_stream(hipStream_t stream);
+// hipMalloc for long-lived tables; trims the cache and retries when HIP runs
+// out of memory
+hipError_t vsa_hip_malloc(void **ptr, size_t bytes);
 
 // builds the deep-locate tables bck2/esa8 from tis/suf/lcp (esa_search.hip);
 // a no-op for alphabets beyond 4 symbols, 64-bit tables or VSA_NO_ESA8=1

@@ -23,6 +23,15 @@ def shard_range(total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
+def selfmum_range(totallength, rank, world):
+    """Part of the self-index MUM scan (Vmengine/fmumself.c:33: i = 2 ..
+    totallength-1) rank scans: (first, last), last exclusive.  The ranges tile
+    the loop; each rank reads lcp/bwt entries i-2 .. i around its ends from its
+    own replica of the index (the halo of SURVEY 8e)."""
+    first, count = shard_range(max(int(totallength) - 2, 0), rank, world)
+    return 2 + first, 2 + first + count
+
+
 def all_reduce_counters(dist, torch, values, device):
     """sum of a handful of uint64 counters over all ranks"""
     t = torch.tensor([int(v) for v in values], dtype=torch.int64,
