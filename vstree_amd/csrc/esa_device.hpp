@@ -523,7 +523,7 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
   uint32_t dl = 0, cnt = 0, qkey = 0, limit = 0;
-  uint64_t first = 0; // esa8[dl] from the fused table
+  uint64_t first = 0, second = 0, third = 0; // esa8[dl..] from the fused table
 
   if (active)
   {
@@ -587,9 +587,17 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
       uint64_t b;
       if (ix.slot16 != nullptr)
       {
-        const vsa_u128 sl = vsa_load16(ix.slot16 + 2 * code);
+        const uint64_t *sp = ix.slot16 + (uint64_t) ix.slotwords * code;
+        const vsa_u128 sl = vsa_load16(sp);
         b = sl.lo;
         first = sl.hi;
+        if (ix.slotwords == 4)
+        {
+          // the other half of the 32-byte slot: same 64-byte sector
+          const vsa_u128 sm = vsa_load16(sp + 2);
+          second = sm.lo;
+          third = sm.hi;
+        }
       } else
       {
         b = vsa_ld_entry(reinterpret_cast<const uint64_t *>(ix.bck2) + code,
@@ -611,13 +619,16 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   const bool small = searching && cnt <= 4;
   const uint32_t ksh = 2 * (VSA_KEYSYMS - limit);
   uint64_t e[5] = {0, 0, 0, 0, 0};
-  if (small && cnt == 1 && ix.slot16 != nullptr)
+  if (small && ix.slot16 != nullptr &&
+      (cnt == 1 || (cnt <= 3 && ix.slotwords == 4)))
   {
-    // a bucket of one suffix: its entry came with the bounds.  The entry
-    // behind it belongs to another bucket and shares fewer than D symbols
-    // with it, so its lcp byte (0 here) is below every match length either
-    // way: nothing else is needed.
+    // the whole bucket came with the bounds.  The entry behind it belongs to
+    // another bucket and shares fewer than D symbols with it, so its lcp byte
+    // (0 here: the table holds 0 for entries the bucket does not have) is
+    // below every match length either way: nothing else is needed.
     e[0] = first;
+    e[1] = second;
+    e[2] = third;
   } else if (small)
   {
     // esa8 has eight entries of slack behind index n

@@ -1620,18 +1620,25 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
             (key << VSA_KEYSHIFT) | flag | left;
 }
 
-// slot16[code] = (bck2 pair, first entry of the bucket)
+// slot[code] = (bck2 pair, the first W-1 entries of the bucket), W = 2 or 4
+// words; entries the bucket does not have are 0 (they stand for the entry
+// behind the bucket, whose lcp byte is below D anyway)
+template <int W>
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_make_slot16(const uint32_t *__restrict__ bck2,
-              const uint64_t *__restrict__ esa8, uint64_t ncodes,
-              uint64_t *__restrict__ slot16)
+k_make_slots(const uint32_t *__restrict__ bck2,
+             const uint64_t *__restrict__ esa8, uint64_t ncodes,
+             uint64_t *__restrict__ slot)
 {
   for (uint64_t c = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
        c < ncodes; c += (uint64_t) gridDim.x * VSA_BLOCK)
   {
     const uint32_t left = bck2[2 * c], mid = bck2[2 * c + 1];
-    slot16[2 * c] = (uint64_t) left | ((uint64_t) mid << 32);
-    slot16[2 * c + 1] = (mid > left) ? esa8[left] : 0;
+    slot[W * c] = (uint64_t) left | ((uint64_t) mid << 32);
+#pragma unroll
+    for (int k = 0; k + 1 < W; k++)
+    {
+      slot[W * c + 1 + k] = (mid > left + k) ? esa8[left + k] : 0;
+    }
   }
 }
 
@@ -1698,21 +1705,48 @@ int vsa_index_make_esa8(vsa_index *ix)
       count, D, ix->esa8);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(ix->stream));
-  // the fused table takes the place of bck2 (16 instead of 8 bytes per deep
-  // prefix); VSA_SLOT16=0 keeps bck2
-  const char *noslot = getenv("VSA_SLOT16");
-  if (!(noslot != nullptr && strcmp(noslot, "0") == 0))
+  // the fused table takes the place of bck2: 16 bytes per deep prefix (bounds
+  // + the first entry: 69 % of the non-empty buckets of a random text are
+  // answered by one access; 68.7 GB at 3 Gbp); VSA_SLOT=32: 32 bytes (bounds +
+  // three entries: 99 %; 137 GB -- measured in round 2: 20 % fewer HBM
+  // sectors in the search kernel and not a microsecond less, because a
+  // second 16-byte load of the same sector is a request of its own and the
+  // kernel is bound by requests in flight, profiles/r02/slot32_ab.txt);
+  // VSA_SLOT=0 keeps bck2.  A wide form is dropped when memory is short.
+  const char *slotenv = getenv("VSA_SLOT");
+  int slotbytes = slotenv != nullptr ? atoi(slotenv) : 16;
+  if (slotbytes != 0 && slotbytes != 16 && slotbytes != 32)
   {
-    VSA_HIP(vsa_hip_malloc((void **) &ix->slot16, 2 * ncodes * 8 + 16));
-    k_make_slot16<<<(unsigned int) std::min<uint64_t>(
-                        (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20),
-                    VSA_BLOCK, 0, ix->stream>>>(ix->bck2, ix->esa8, ncodes,
-                                                ix->slot16);
+    slotbytes = 16;
+  }
+  for (; slotbytes >= 16; slotbytes -= 16)
+  {
+    const uint32_t words = (uint32_t) slotbytes / 8;
+    if (vsa_hip_malloc((void **) &ix->slot16, words * ncodes * 8 + 32) !=
+        hipSuccess)
+    {
+      (void) hipGetLastError();
+      ix->slot16 = nullptr;
+      continue;
+    }
+    const unsigned int grid = (unsigned int) std::min<uint64_t>(
+        (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20);
+    if (words == 4)
+    {
+      k_make_slots<4><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          ix->bck2, ix->esa8, ncodes, ix->slot16);
+    } else
+    {
+      k_make_slots<2><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          ix->bck2, ix->esa8, ncodes, ix->slot16);
+    }
     VSA_HIP(hipGetLastError());
     VSA_HIP(hipStreamSynchronize(ix->stream));
     (void) hipFree(ix->bck2);
     ix->bck2 = nullptr;
-    ix->device_bytes += 2 * ncodes * 4;
+    ix->slotwords = words;
+    ix->device_bytes += (uint64_t) words * ncodes * 8 - 2 * ncodes * 4;
+    break;
   }
   return 0;
 }

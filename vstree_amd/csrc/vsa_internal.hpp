@@ -68,6 +68,7 @@ struct DevIndex
   // when present (a bucket of one suffix -- the usual non-empty bucket --
   // then needs no second access)
   const uint64_t *slot16;
+  uint32_t slotwords; // 2: bounds + first entry; 4: bounds + three entries
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars, D;
   uint32_t tune; // experiment switches (VSA_TUNE), see esa_search.hip
@@ -96,6 +97,7 @@ struct vsa_index
   uint64_t *esa8; // deep-locate tables, see DevIndex (may be nullptr)
   uint32_t *bck2;
   uint64_t *slot16;
+  uint32_t slotwords;
   uint32_t D, tune;
   uint32_t qspeedup; // vsa_index_set_queryspeedup: 0 or 2 (default)
   uint64_t querysepposition;
@@ -119,6 +121,7 @@ struct vsa_index
     v.esa8 = esa8;
     v.bck2 = bck2;
     v.slot16 = slot16;
+    v.slotwords = slotwords;
     v.D = D;
     v.tune = tune;
     v.qspeedup = qspeedup;
