@@ -630,7 +630,7 @@ def test_wide_device_tables(V, case, monkeypatch):
         assert np.array_equal(got, want), (case, key)
 
 
-@pytest.mark.parametrize("tune", [2, 4, 8, 16, 32])
+@pytest.mark.parametrize("tune", [2, 4, 8, 16, 32, 64])
 def test_older_work_reduction_paths_still_agree(V, tune, monkeypatch):
     """VSA_TUNE bits 1-3 switch the first pass / the plan / all work
     reduction off, bit 4 the packed candidate pairs of the MUM filter, bit 5

@@ -226,6 +226,8 @@ extern "C" void vsa_index_close(vsa_index *ix)
   (void) hipFree(ix->esa8);
   (void) hipFree(ix->bck2);
   (void) hipFree(ix->slot16);
+  (void) hipFree(ix->tis2);
+  (void) hipFree(ix->spec64);
   if (ix->stream != nullptr)
   {
     vsa_dev_forget_stream(ix->stream);

@@ -207,6 +207,144 @@ __device__ __forceinline__ int vsa_compare32(const DevIndex<IDX> &ix,
   }
 }
 
+// four symbols (the bytes of h, first symbol in the lowest) -> 8 bits in the
+// TOP byte of the result, first symbol most significant; the bytes below are
+// scrap.  One multiplication lines the four 2-bit fields up: byte k moves by
+// 30 - 10k bits, and none of the other partial products reaches bit 24.
+__device__ __forceinline__ uint32_t vsa_pack4top(uint32_t h)
+{
+  return (h & 0x03030303u) * 0x40100401u;
+}
+
+// 16 symbols (bytes 0..3 each, two words) -> 32 bits, first symbol in the top two
+__device__ __forceinline__ uint32_t vsa_pack16(uint64_t a, uint64_t b)
+{
+  return (vsa_pack4top((uint32_t) a) & 0xFF000000u) |
+         ((vsa_pack4top((uint32_t) (a >> 32)) >> 8) & 0x00FF0000u) |
+         ((vsa_pack4top((uint32_t) b) >> 16) & 0xFF00u) |
+         (vsa_pack4top((uint32_t) (b >> 32)) >> 24);
+}
+
+// Continues the comparison of query[lcplen..querylen) with the suffix at
+// sufstart on the 2-bit text (DevIndex::tis2): 60 symbols per 16-byte load of
+// the text instead of 16.  Returns false if the answer needs the bytes -- a
+// block of the text it touched holds a special symbol or the end of the text
+// (the caller repeats the comparison with vsa_compare32) -- and otherwise
+// leaves in lcplen what COMPARE / CHECKRETURN (kurtz/maxpref.c:30-65) would:
+// the position of the first mismatch, of the first special symbol of the
+// query, or querylen.  CHUNKS: pieces of 60 symbols fetched per round trip.
+template <int CHUNKS>
+__device__ __forceinline__ bool
+vsa_extend_packed(const DevIndex<uint32_t> &ix, uint64_t sufstart,
+                  const uint8_t *query, uint32_t querylen, uint32_t &lcplen)
+{
+  const uint32_t from = lcplen;
+  uint32_t l = lcplen, qeff = querylen;
+  bool open = true; // no mismatch seen yet
+
+  // the packed text knows no end: a comparison that reaches position n stops
+  // there, and the block that holds n sends it to the bytes
+  if ((uint64_t) qeff > ix.n - sufstart)
+  {
+    qeff = (uint32_t) (ix.n - sufstart);
+  }
+
+  while (open && l < qeff)
+  {
+    uint64_t A[CHUNKS][2], Q[CHUNKS][2];
+    uint32_t bad[CHUNKS];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+    {
+      const uint32_t lc = l + 60u * (uint32_t) c;
+      bad[c] = 64;
+      A[c][0] = A[c][1] = Q[c][0] = Q[c][1] = 0;
+      if (c == 0 || lc < qeff)
+      {
+        const uint64_t pos = sufstart + lc;
+        const uint32_t sh = 2u * (uint32_t) (pos & 3u);
+        const vsa_u128 t = vsa_load16(ix.tis2 + (pos >> 2));
+        const uint64_t t0 = __builtin_bswap64(t.lo),
+                       t1 = __builtin_bswap64(t.hi);
+        A[c][0] = sh != 0 ? (t0 << sh) | (t1 >> (64 - sh)) : t0;
+        A[c][1] = t1 << sh;
+        // 16-byte pieces of the query behind its end are not fetched
+        const vsa_u128 zero = {0, 0};
+        const vsa_u128 q0 = vsa_load16(query + lc),
+                       q1 = lc + 16 < qeff ? vsa_load16(query + lc + 16) : zero,
+                       q2 = lc + 32 < qeff ? vsa_load16(query + lc + 32) : zero,
+                       q3 = lc + 48 < qeff ? vsa_load16(query + lc + 48) : zero;
+        Q[c][0] = ((uint64_t) vsa_pack16(q0.lo, q0.hi) << 32) |
+                  vsa_pack16(q1.lo, q1.hi);
+        Q[c][1] = ((uint64_t) vsa_pack16(q2.lo, q2.hi) << 32) |
+                  vsa_pack16(q3.lo, q3.hi);
+        // first byte of the query piece that is no DNA symbol
+        const uint64_t notdna = 0xFCFCFCFCFCFCFCFCull;
+        const uint64_t w[8] = {q0.lo, q0.hi, q1.lo, q1.hi,
+                               q2.lo, q2.hi, q3.lo, q3.hi};
+#pragma unroll
+        for (int k = 7; k >= 0; k--)
+        {
+          const uint64_t s = w[k] & notdna;
+          if (s != 0)
+          {
+            bad[c] = 8u * (uint32_t) k + ((uint32_t) __builtin_ctzll(s) >> 3);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+    {
+      if (open && l < qeff)
+      {
+        if (bad[c] < 60 && l + bad[c] < qeff)
+        {
+          qeff = l + bad[c]; // the comparison ends at a special query symbol
+        }
+        const uint64_t x0 = A[c][0] ^ Q[c][0],
+                       x1 = (A[c][1] ^ Q[c][1]) & ~0xFFull; // 28 symbols
+        uint32_t same = 60;
+        if (x0 != 0)
+        {
+          same = (uint32_t) __builtin_clzll(x0) >> 1;
+        } else if (x1 != 0)
+        {
+          same = 32 + ((uint32_t) __builtin_clzll(x1) >> 1);
+        }
+        l += same;
+        open = same == 60;
+      }
+    }
+  }
+  if (l > qeff)
+  {
+    l = qeff;
+  }
+  // did the comparison touch a block with a special symbol (packed as 0)?
+  if (sufstart + l + 64 >= ix.firstspecial)
+  {
+    uint64_t b = (sufstart + from) >> 6;
+    const uint64_t blast = (sufstart + l) >> 6;
+    while (b <= blast)
+    {
+      uint32_t bits;
+      __builtin_memcpy(&bits, ix.spec64 + (b >> 3), 4);
+      bits >>= (uint32_t) (b & 7u);
+      const uint64_t have = 25, want = blast - b + 1;
+      const uint32_t mask = want >= have ? (1u << have) - 1u
+                                         : (1u << want) - 1u;
+      if ((bits & mask) != 0)
+      {
+        return false;
+      }
+      b += have;
+    }
+  }
+  lcplen = l;
+  return true;
+}
+
 // table accessors: esa8 carries suf and the lcp byte next to each other
 template <typename IDX, bool KEYED>
 __device__ __forceinline__ uint64_t vsa_sufstart(const DevIndex<IDX> &ix,
@@ -449,15 +587,6 @@ __device__ __forceinline__ uint64_t vsa_pack8(uint64_t w)
   return x;
 }
 
-// four symbols (the bytes of h, first symbol in the lowest) -> 8 bits in the
-// TOP byte of the result, first symbol most significant; the bytes below are
-// scrap.  One multiplication lines the four 2-bit fields up: byte k moves by
-// 30 - 10k bits, and none of the other partial products reaches bit 24.
-__device__ __forceinline__ uint32_t vsa_pack4top(uint32_t h)
-{
-  return (h & 0x03030303u) * 0x40100401u;
-}
-
 // number of leading key symbols (2 bits each, `nsyms` of them in the low
 // bits of a and b) that agree
 __device__ __forceinline__ uint32_t vsa_keylcp(uint32_t a, uint32_t b,
@@ -477,7 +606,10 @@ enum
 {
   VSA_LOC_NONE = 0, // nothing in the index shares D symbols with the query
   VSA_LOC_FOUND = 1,
-  VSA_LOC_SLOW = 2  // take the reference walk (special symbols, ties, ...)
+  VSA_LOC_SLOW = 2, // take the reference walk (special symbols, ties, ...)
+  // (DEFER only) located, but the matched length needs the comparison on the
+  // text: maxlcp = the symbols known to match, w / hit as for FOUND
+  VSA_LOC_DEFER = 3
 };
 
 // Deep locate.  Must be called by all lanes of the wavefront (inactive lanes
@@ -500,7 +632,7 @@ struct DeepHit
   bool notleftmax;  // see vsa_locate_deep, qleft
 };
 
-template <int AHEAD = 1>
+template <int AHEAD = 1, bool DEFER = false>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
@@ -802,12 +934,32 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
       extend = false;
     }
   }
-  // one text comparison for the lanes with a tie, all at the same time
+  // one text comparison for the lanes with a tie, all at the same time --
+  // or, DEFER, none here: the few lanes with a tie (true matches, usually
+  // long) leave for a kernel of their own instead of holding up the
+  // wavefront, whose other lanes are done
+  if (DEFER)
+  {
+    return (state == VSA_LOC_FOUND && extend) ? VSA_LOC_DEFER : state;
+  }
   if (extend)
   {
     uint32_t lcplen = maxlcp;
-    (void) vsa_compare32<uint32_t, AHEAD>(ix, esucc & 0xFFFFFFFFull, query,
-                                          querylen, lcplen);
+    // on the 2-bit text where there is one (two pieces of 60 symbols per
+    // round trip when the caller expects long matches); lanes whose
+    // comparison met a special symbol of the text repeat it on the bytes
+    bool done = false;
+    if (ix.tis2 != nullptr)
+    {
+      done = vsa_extend_packed<(AHEAD > 1 ? 2 : 1)>(
+          ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
+    }
+    if (!done)
+    {
+      lcplen = maxlcp;
+      (void) vsa_compare32<uint32_t, AHEAD>(ix, esucc & 0xFFFFFFFFull, query,
+                                            querylen, lcplen);
+    }
     maxlcp = lcplen;
   }
   return state;

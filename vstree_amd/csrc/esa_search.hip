@@ -1191,6 +1191,32 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           ? lenbits
           : 0;
   const size_t recsize = valbits != 0 ? 4 : (packed ? 8 : sizeof(vsa_match));
+  // MUM search on the deep tables, VSA_TUNE bit 6 (experiment, off by
+  // default): work-items whose matched length needs the text (true matches, 3
+  // in 100) go to a list and get a kernel of their own (k_query_deferred).  A
+  // region of the list holds every item of the workgroups that write to it,
+  // so it cannot overflow.  Measured in round 2 (profiles/r02/
+  // k2_deferral_ab.txt): the search kernel loses a third of its vector memory
+  // instructions and 8 % of its time, the second kernel takes that back.
+  const unsigned int qblk =
+      (qblock == 64 || qblock == 128 || qblock == 512) ? (unsigned) qblock
+                                                        : 256u;
+  const uint64_t nblocksq = (nwork + qblk - 1) / qblk,
+                 defcap = ((nblocksq + nshards - 1) / nshards) * qblk;
+  bool defer = false;
+  if constexpr (sizeof(IDX) == 4)
+  {
+    defer = domum && deepok && nwork > 0 && (index->tune & 64u) != 0 &&
+            queries->maxlength < 0xFFFFu && queries->nq < 0xFFFFFFFFull &&
+            nshards * defcap * 20 <= (8ull << 30);
+  }
+  DevBuf defrec, defw, defcursor;
+  if (defer && (defrec.alloc(nshards * defcap * sizeof(DeferredSearch)) ||
+                defw.alloc(nshards * defcap * 4) ||
+                defcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8)))
+  {
+    return -100;
+  }
   for (int attempt = 0; attempt < 2; attempt++)
   {
     if (rawout.alloc(nshards * shardcap * recsize) ||
@@ -1200,10 +1226,20 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipMemsetAsync(cursor.p, 0,
                            (size_t) nshards * VSA_CURSOR_STRIDE * 8, stream));
+    if (defer)
+    {
+      VSA_HIP(hipMemsetAsync(defcursor.p, 0,
+                             (size_t) nshards * VSA_CURSOR_STRIDE * 8,
+                             stream));
+    }
+    // experiment switch: VSA_K2_LDS bytes of unused dynamic LDS per workgroup
+    // cut the resident wavefronts (occupancy sweeps, profiles/r02)
+    const char *ldsenv = getenv("VSA_K2_LDS");
+    const size_t k2lds = ldsenv != nullptr ? (size_t) atol(ldsenv) : 0;
     tsearch.start();
 #define VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, BLK)                              \
   k_query_search<IDX, MUMFLAG, KEYFLAG, BLK>                                  \
-      <<<(unsigned int) ((nwork + BLK - 1) / BLK), BLK, 0, stream>>>(         \
+      <<<(unsigned int) ((nwork + BLK - 1) / BLK), BLK, k2lds, stream>>>(     \
           ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
@@ -1231,7 +1267,38 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       deep = deep || deepok;
       if (deep && nwork > 0)
       {
-        if (domum)
+        if (domum && defer)
+        {
+#define VSA_LAUNCH_DEFER(BLK)                                                  \
+  k_query_search<IDX, true, true, BLK, true>                                  \
+      <<<(unsigned int) nblocksq, BLK, k2lds, stream>>>(                      \
+          ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
+          rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
+          nshards - 1, cursor.as<unsigned long long>(), packbits, valbits,    \
+          defrec.as<DeferredSearch>(), defw.as<uint32_t>(), defcap,           \
+          defcursor.as<unsigned long long>())
+          if (qblk == 64)
+          {
+            VSA_LAUNCH_DEFER(64);
+          } else if (qblk == 128)
+          {
+            VSA_LAUNCH_DEFER(128);
+          } else if (qblk == 512)
+          {
+            VSA_LAUNCH_DEFER(512);
+          } else
+          {
+            VSA_LAUNCH_DEFER(256);
+          }
+#undef VSA_LAUNCH_DEFER
+          VSA_HIP(hipGetLastError());
+          k_query_deferred<256><<<nshards, 256, 0, stream>>>(
+              ix, qs, dbase, perquery, searchlength,
+              defrec.as<DeferredSearch>(), defw.as<uint32_t>(), defcap,
+              defcursor.as<unsigned long long>(), rawout.as<vsa_match>(),
+              rawkeys.as<uint64_t>(), shardcap,
+              cursor.as<unsigned long long>(), packbits, valbits);
+        } else if (domum)
         {
           VSA_LAUNCH_QUERY(true, true);
         } else
@@ -1620,6 +1687,53 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
             (key << VSA_KEYSHIFT) | flag | left;
 }
 
+// tis2 / spec64 / firstspecial (see DevIndex): one work-item packs a block of
+// 64 text positions into 16 bytes; the wavefront's ballot is 8 bytes of the
+// block bitmap.  Positions >= n count as special.
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_pack_text(const uint8_t *__restrict__ tis, uint64_t n, uint64_t nblocks,
+            uint8_t *__restrict__ tis2, uint8_t *__restrict__ spec64,
+            unsigned long long *__restrict__ firstspecial)
+{
+  const uint64_t b = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  bool special = false;
+  if (b < nblocks)
+  {
+    const uint8_t *p = tis + 64 * b; // 0xFF behind position n
+    uint64_t out[2] = {0, 0}, firstbad = ~0ull;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const vsa_u128 v = vsa_load16(p + 16 * k);
+      const uint64_t notdna = 0xFCFCFCFCFCFCFCFCull;
+      const uint64_t s0 = v.lo & notdna, s1 = v.hi & notdna;
+      if (firstbad == ~0ull && (s0 | s1) != 0)
+      {
+        firstbad = 64 * b + 16 * k +
+                   (s0 != 0 ? ((uint64_t) __builtin_ctzll(s0) >> 3)
+                            : 8 + ((uint64_t) __builtin_ctzll(s1) >> 3));
+      }
+      const uint64_t packed = vsa_pack16(v.lo, v.hi); // 16 symbols, 32 bits
+      out[k >> 1] |= packed << (32 * (1 - (k & 1)));
+    }
+    // first symbol in the top bits of the first byte
+    out[0] = __builtin_bswap64(out[0]);
+    out[1] = __builtin_bswap64(out[1]);
+    reinterpret_cast<uint64_t *>(tis2)[2 * b] = out[0];
+    reinterpret_cast<uint64_t *>(tis2)[2 * b + 1] = out[1];
+    special = firstbad != ~0ull || 64 * b + 64 > n;
+    if (firstbad != ~0ull)
+    {
+      atomicMin(firstspecial, (unsigned long long) firstbad);
+    }
+  }
+  const uint64_t mask = __ballot(special);
+  if ((threadIdx.x & 63) == 0 && b < nblocks)
+  {
+    reinterpret_cast<uint64_t *>(spec64)[b >> 6] = mask;
+  }
+}
+
 // slot[code] = (bck2 pair, the first W-1 entries of the bucket), W = 2 or 4
 // words; entries the bucket does not have are 0 (they stand for the entry
 // behind the bucket, whose lcp byte is below D anyway)
@@ -1659,6 +1773,12 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     (void) hipFree(ix->slot16);
     ix->slot16 = nullptr;
+  }
+  if (ix->tis2 != nullptr)
+  {
+    (void) hipFree(ix->tis2);
+    (void) hipFree(ix->spec64);
+    ix->tis2 = ix->spec64 = nullptr;
   }
   if (ix->numofchars != 4 || ix->isize != 4 || ix->bck == nullptr ||
       (off != nullptr && strcmp(off, "1") == 0))
@@ -1705,6 +1825,34 @@ int vsa_index_make_esa8(vsa_index *ix)
       count, D, ix->esa8);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(ix->stream));
+  // the 2-bit text for long comparisons (VSA_PACKED_TEXT=0: without)
+  const char *nopack = getenv("VSA_PACKED_TEXT");
+  if (!(nopack != nullptr && strcmp(nopack, "0") == 0))
+  {
+    // blocks 0 .. n >> 6: a comparison ends at position n at the latest (the
+    // last block reads into the 0xFF padding behind the text, not beyond it)
+    static_assert(VSA_TIS_BACKPAD >= 64, "text pad too small for k_pack_text");
+    const uint64_t nblocks = (ix->n >> 6) + 1,
+                   nwaves = (nblocks + 63) / 64;
+    unsigned long long *dfirst = nullptr, hfirst = ix->n;
+    VSA_HIP(vsa_hip_malloc((void **) &ix->tis2, nblocks * 16 + 64));
+    VSA_HIP(vsa_hip_malloc((void **) &ix->spec64, nwaves * 8 + 64));
+    VSA_HIP(vsa_hip_malloc((void **) &dfirst, 8));
+    VSA_HIP(hipMemsetAsync(ix->tis2 + nblocks * 16, 0, 64, ix->stream));
+    VSA_HIP(hipMemsetAsync(ix->spec64 + nwaves * 8, 0xFF, 64, ix->stream));
+    VSA_HIP(hipMemcpyAsync(dfirst, &hfirst, 8, hipMemcpyHostToDevice,
+                           ix->stream));
+    k_pack_text<<<(unsigned int) (nwaves * 64 / VSA_BLOCK + 1), VSA_BLOCK, 0,
+                  ix->stream>>>(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
+                                nblocks, ix->tis2, ix->spec64, dfirst);
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipMemcpyAsync(&hfirst, dfirst, 8, hipMemcpyDeviceToHost,
+                           ix->stream));
+    VSA_HIP(hipStreamSynchronize(ix->stream));
+    (void) hipFree(dfirst);
+    ix->firstspecial = hfirst < ix->n ? hfirst : ix->n;
+    ix->device_bytes += nblocks * 16 + nwaves * 8;
+  }
   // the fused table takes the place of bck2: 16 bytes per deep prefix (bounds
   // + the first entry: 69 % of the non-empty buckets of a random text are
   // answered by one access; 68.7 GB at 3 Gbp); VSA_SLOT=32: 32 bytes (bounds +

@@ -69,6 +69,15 @@ struct DevIndex
   // then needs no second access)
   const uint64_t *slot16;
   uint32_t slotwords; // 2: bounds + first entry; 4: bounds + three entries
+  // Long comparisons on a quarter of the bytes (DNA): tis2 = the text with
+  // 2 bits per symbol, four symbols per byte, the first in the top bits
+  // (special symbols stand as 0); spec64 = one bit per block of 64 text
+  // positions, set if the block holds a special symbol or reaches beyond the
+  // text, so that a comparison that touched such a block is repeated on the
+  // bytes; firstspecial = the first position that is special (n if none)
+  const uint8_t *tis2;
+  const uint8_t *spec64;
+  uint64_t firstspecial;
   uint64_t n, nllv, numofcodes;
   uint32_t pl, numofchars, D;
   uint32_t tune; // experiment switches (VSA_TUNE), see esa_search.hip
@@ -98,6 +107,8 @@ struct vsa_index
   uint32_t *bck2;
   uint64_t *slot16;
   uint32_t slotwords;
+  uint8_t *tis2, *spec64; // see DevIndex (may be nullptr)
+  uint64_t firstspecial;
   uint32_t D, tune;
   uint32_t qspeedup; // vsa_index_set_queryspeedup: 0 or 2 (default)
   uint64_t querysepposition;
@@ -122,6 +133,9 @@ struct vsa_index
     v.bck2 = bck2;
     v.slot16 = slot16;
     v.slotwords = slotwords;
+    v.tis2 = tis2;
+    v.spec64 = spec64;
+    v.firstspecial = firstspecial;
     v.D = D;
     v.tune = tune;
     v.qspeedup = qspeedup;
