@@ -16,17 +16,29 @@ scaling).  Phase 1 (search) needs no communication; the MUM uniqueness filter
 (kurtz/cleanMUMcand.c of the reference) is one global step: candidates are
 range-partitioned by database position over the ranks (RCCL all-to-all), every
 rank filters its range with the carry of the lower ranges; one RCCL all-reduce
-sums the match counters.
+sums the match counters.  `--mode selfmum` runs the other sharded path of
+SURVEY 8e instead: the self-index MUM scan split into suffix-array ranges.
 
-Prints ONE JSON line on rank 0.  Extra objects: "roofline" (dominant kernel
-k_query_search, algorithmic bytes from the instrumented CPU restatement) and
-"cpu_baseline" (rank 0, N = 1: the CPU oracle = port of the reference's
-default algorithm, one core, on a bounded sample of the same batch).
+Prints ONE JSON line on rank 0.  Everything in it is measured in this run:
+  roofline           the dominant kernel (k_query_search), HIP-event time
+  roofline_families  the same for the other kernel families of the path --
+                     first pass, -complete (K1), MEM, -complete -e 2 (piece
+                     search and banded alignment), the self-index scan (K3)
+  cpu_baseline       the reference program (oracle/_ref/vmatch_ref, built from
+                     the reference's sources, index files written by
+                     vsa_mkvtree) on P = all host cores given to the box
+                     (P processes over 1/P of the sample each, wall = slowest)
+                     and on one core; the CPU restatement (oracle) on one core
+`--quick` leaves the extra families and the reference program out (A/B runs,
+profiling passes).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -54,9 +66,16 @@ def parse():
                     help="queries per GPU (default 10 M)")
     ap.add_argument("--qlen", type=int, default=100)
     ap.add_argument("--minlen", type=int, default=20, help="vmatch -l")
-    ap.add_argument("--cpu-sample", type=int, default=1000000,
-                    help="queries timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-cores", type=int, default=1)
+    ap.add_argument("--mode", choices=("mum", "selfmum"), default="mum")
+    ap.add_argument("--cpu-sample", type=int, default=500000,
+                    help="queries timed on one CPU core (0 = no CPU baseline)")
+    ap.add_argument("--ref-sample", type=int, default=2000000,
+                    help="queries given to the P reference processes together")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline step and its roofline only")
+    ap.add_argument("--no-reference", action="store_true",
+                    help="do not run oracle/_ref/vmatch_ref")
+    ap.add_argument("--workdir", default="/dev/shm")
     # rehearsal of the N > 1 path on a box with ONE GPU: every rank uses
     # device 0 and the collectives run over gloo on host copies
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
@@ -66,21 +85,152 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(H, host_index, sample, minlen, w):
-    """bytes the search has to touch per query, counted by the instrumented
-    CPU restatement running the GPU's algorithm (bucket + binary search per
-    query suffix): per search 2w (bck pair) + probes*w
-    (suf) + compared symbols (tis) + lcp entries; per query its m symbols;
-    per reported match w (suf) + 1 (left symbol) + 32 (record written)."""
+def kernel_source_hash():
+    """identifies the kernel sources a PMC profile was taken with"""
+    h = hashlib.sha1()
+    for f in ("search_query.inc", "esa_device.hpp", "mum_workplan.inc",
+              "esa_search.hip"):
+        with open(os.path.join(ROOT, "vstree_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def count_bytes(H, run, nq, w, symbols):
+    """bytes the reference's algorithm touches per query, counted by the
+    instrumented CPU restatement: per search 2w (bck
+    pair) + probes*w (suf) + compared symbols (tis) + lcp entries; per query
+    its symbols; per reported match w (suf) + 1 (left symbol) + 32 (record)."""
     H.oracle_counters(reset=True)
-    H.oracle_querymatches(host_index, sample, minlen, mum=True, cand=True,
-                          speedup=0)
+    run()
     c = H.oracle_counters(reset=True)
-    nq = sample.nq
     total = (c["bckreads"] * 2 * w + c["sufprobes"] * w + c["charcomp"] +
-             c["lcpreads"] + int(sample.length.sum()) +
-             c["emitted"] * (w + 1 + 32))
+             c["lcpreads"] + symbols + c["emitted"] * (w + 1 + 32))
     return total / nq, c
+
+
+def family(name, mode, ms, nbytes, note, **more):
+    ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    d = {"kernel": name, "mode": mode, "bound": "hbm", "achieved": ach,
+         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "kernel_ms": ms,
+         "algorithmic_bytes_per_launch": nbytes, "note": note}
+    d.update(more)
+    return d
+
+
+def write_fasta(path, header, symbols, width=1 << 20):
+    letters = np.frombuffer(b"acgt", np.uint8)
+    with open(path, "wb") as f:
+        f.write(header)
+        n = len(symbols)
+        for i in range(0, n, width << 6):
+            chunk = letters[symbols[i:i + (width << 6)]]
+            k = (len(chunk) // width) * width
+            if k:
+                rows = chunk[:k].reshape(-1, width)
+                nl = np.full((rows.shape[0], 1), 10, np.uint8)
+                f.write(np.hstack([rows, nl]).tobytes())
+            if k < len(chunk):
+                f.write(chunk[k:].tobytes() + b"\n")
+
+
+def write_queries(path, qsym, m, first, count):
+    letters = np.frombuffer(b"acgt", np.uint8)
+    rows = letters[qsym[first * m:(first + count) * m]].reshape(count, m)
+    with open(path, "wb") as f:
+        out = []
+        for i in range(count):
+            out.append(b">q%d\n" % (first + i))
+            out.append(rows[i].tobytes())
+            out.append(b"\n")
+        f.write(b"".join(out))
+
+
+def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
+    """oracle/_ref/vmatch_ref on this box's host cores.  Returns a dict or
+    None (binary missing / no room for the 64-bit index files)."""
+    n = len(genome)
+    if a.no_reference or not os.access(H.VMATCH_REF, os.X_OK):
+        return None
+    need = 16 * n + (2 << 30)
+    if shutil.disk_usage(a.workdir).free < need:
+        log("reference baseline skipped: %s has less than %.0f GB free"
+            % (a.workdir, need / 1e9))
+        return None
+    wd = os.path.join(a.workdir, "vsa_bench_%d" % os.getpid())
+    os.makedirs(wd)
+    try:
+        t0 = time.time()
+        write_fasta(wd + "/genome.fna", b">synthetic_genome seed=42\n", genome)
+        # the index files the reference maps: vsa_mkvtree (GPU build, files
+        # byte-identical to mkvtree's, tests/test_gpu_mkvtree.py), 64-bit
+        # integers like the reference's LP64 build
+        V.mkvtree([wd + "/genome.fna"], wd + "/genome.fna", integersize=64,
+                  withskp=False)
+        t_index = time.time() - t0
+        ns1 = min(a.cpu_sample, len(qsym) // m)
+        nsp = min(a.ref_sample, len(qsym) // m)
+        per = nsp // ncores
+        nsp = per * ncores
+        write_queries(wd + "/q1.fna", qsym, m, 0, ns1)
+        for p in range(ncores):
+            write_queries(wd + "/qp%d.fna" % p, qsym, m, p * per, per)
+        env = dict(os.environ, VMATCHSHOWTIMESPACE="on")
+        args = [H.VMATCH_REF, "-mum", "-l", str(L), "-q"]
+
+        def run(files):
+            t = time.time()
+            procs = [subprocess.Popen(args + [f, "genome.fna"], cwd=wd,
+                                      env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL)
+                     for f in files]
+            counts = []
+            for p in procs:
+                out = p.communicate()[0]
+                if p.returncode != 0:
+                    raise RuntimeError("vmatch_ref failed")
+                counts.append(sum(1 for l in out.splitlines()
+                                  if l and not l.startswith(b"#")))
+            return time.time() - t, counts
+        # page the index files in (pumpthroughcache, readvirt.c:567-678, by a
+        # short run), then time
+        write_queries(wd + "/warm.fna", qsym, m, 0, min(20000, ns1))
+        run(["warm.fna"])
+        t1, c1 = run(["q1.fna"])
+        tp, cp = run(["qp%d.fna" % p for p in range(ncores)])
+        log("reference vmatch: index files %.0f s, 1 core %.1f s (%d queries),"
+            " %d cores %.1f s (%d queries)" % (t_index, t1, ns1, ncores, tp,
+                                               nsp))
+        return {
+            "value": nsp / tp, "unit": "queries/s", "cores": ncores,
+            "kind": "reference",
+            "sample": "vmatch -mum -l %d (default -qspeedup 2) of the "
+                      "reference built from its own sources (oracle/_ref), "
+                      "%d processes x %d queries of the same batch on the "
+                      "same %.2g bp index (files written by vsa_mkvtree, "
+                      "64-bit; %d hardware threads visible, %d = the share "
+                      "of one GPU used), whole processes incl. FASTA parsing "
+                      "and output, wall of the slowest = %.1f s; %d MUMs"
+                      % (L, ncores, per, n, len(os.sched_getaffinity(0)),
+                         ncores, tp, sum(cp)),
+            "reference_1core": {
+                "value": ns1 / t1, "unit": "queries/s", "cores": 1,
+                "kind": "reference",
+                "sample": "%d queries, one process, %.1f s, %d MUMs"
+                          % (ns1, t1, c1[0])},
+            "mums_1core_sample": c1[0]}
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+
+
+def selfmum_text(V, n):
+    """db half + separator + a copy with one substitution every 97 bp: every
+    suffix pair is an lcp peak (the dense case of scripts/selfmum_probe.py)"""
+    half = (n - 1) // 2
+    g = V.synth_genome(half)
+    g2 = g.copy()
+    g2[::97] = (g2[::97] + 1) & 3
+    return np.concatenate([g, np.array([255], np.uint8), g2]), half
 
 
 def main():
@@ -117,6 +267,8 @@ def main():
                                 rank=rank, world_size=world)
 
     n, nq, m, L = int(a.genome), int(a.queries), a.qlen, a.minlen
+    if a.mode == "selfmum":
+        return selfmum_mode(a, V, S, torch, dist, rank, world, dev, jsonfd)
 
     # ---- setup (untimed): genome, index, this rank's queries, all in HBM --
     t0 = time.time()
@@ -136,6 +288,18 @@ def main():
     queries = V.Queries.from_device(dq, nq, m, dev)
     queries.set_offset(rank * nq)
     V.device_free(dq, dev)
+    extras = rank == 0 and world == 1 and not a.quick
+    q150 = None
+    if extras:
+        # BASELINE configs[4]: 150 bp reads of the same genome
+        p5, s5, st5 = V.synth_query_plan(n, nq, 150)
+        dq = V.device_malloc(nq * 150 + 64, dev)
+        V._check(V.lib.vsa_synth_queries_device(dg, n, p5.ctypes.data,
+                                                s5.ctypes.data,
+                                                st5.ctypes.data, nq, 150, dq,
+                                                dev))
+        q150 = V.Queries.from_device(dq, nq, 150, dev)
+        V.device_free(dq, dev)
     V.device_free(dg, dev)
     if rank == 0:
         log("setup: index %d bp (prefixlength %d, %.1f GB in HBM) built in "
@@ -158,7 +322,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    kernel_ms, totals = [], None
+    kernel_ms, first_ms, totals = [], [], None
 
     def one_step():
         """the hot path over the whole batch; returns (count, sumlength,
@@ -168,6 +332,7 @@ def main():
             r = V.findquerymatches(index, queries, L, mum=True)
             s = r.stats()
             kernel_ms.append(s.search_kernel_ms)
+            first_ms.append(s.first_kernel_ms)
             totals = (s.count, s.sumlength, s.searches, s.candidates,
                       s.kernel_searches)
             r.close()
@@ -179,6 +344,7 @@ def main():
         r = V.findmumcandidates_packed(index, queries, L, lenbits)
         s = r.stats()
         kernel_ms.append(s.search_kernel_ms)
+        first_ms.append(s.first_kernel_ms)
         mine = torch.empty(max(r.count, 1) * 2, dtype=torch.int64,
                            device="cuda")[:r.count * 2]
         send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()))
@@ -207,6 +373,7 @@ def main():
     for _ in range(a.warmup):
         one_step()
     kernel_ms.clear()
+    first_ms.clear()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -223,6 +390,7 @@ def main():
     total_queries = nq * world
     qps = total_queries * a.steps / elapsed
     kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    fms = float(np.mean(first_ms)) if first_ms else float("nan")
 
     out = {
         "metric": "queries/sec (100 bp queries, vmatch -mum -l 20 "
@@ -254,93 +422,296 @@ def main():
         t = index.download()
         host = H.Index(n, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
                        t["llv"], t["bck"], t["bwt"], None)
-        qsym = np.zeros(min(nq, max(a.cpu_sample, 20000)) * m, np.uint8)
+        nsample = min(nq, max(a.cpu_sample, a.ref_sample if extras else 0,
+                              20000))
+        qsym = np.zeros(nsample * m, np.uint8)
         g = t["tis"]
-        ns = qsym.shape[0] // m
-        for i in range(ns):   # the same queries the GPU has, from the plan
-            p = int(pos[i])
-            qsym[i * m:(i + 1) * m] = g[p:p + m]
-            if sub[i] != V.NO_SUBST:
-                k = i * m + int(sub[i])
-                qsym[k] = (qsym[k] + step[i]) & 3
+        rows = qsym.reshape(nsample, m)
+        idx = pos[:nsample, None].astype(np.int64) + np.arange(m)[None, :]
+        rows[:] = g[idx]            # the same queries the GPU has
+        hit = np.flatnonzero(sub[:nsample] != V.NO_SUBST)
+        rows[hit, sub[hit]] = (rows[hit, sub[hit]] + step[hit]) & 3
+        del idx
         small = H.Queries.uniform(qsym[:20000 * m], m)
-        bytes_per_query, counters = algorithmic_bytes(H, host, small, L, w)
+        bytes_per_query, counters = count_bytes(
+            H, lambda: H.oracle_querymatches(host, small, L, mum=True,
+                                             cand=True, speedup=0),
+            small.nq, w, int(small.length.sum()))
         # SURVEY 8d / BASELINE.md: bytes of the reference's per-suffix
         # algorithm (one bucket lookup + binary search for EVERY query
         # suffix) x queries per launch
         alg0_bytes_launch = bytes_per_query * nq
         full_searches = nq * (m - L + 1)
-        # the dominant kernel only runs the searches the anchor pass and the
+        # the dominant kernel only runs the searches the first pass and the
         # work plan left over; price it on that work, not on work they
         # proved unnecessary
         main_searches = kernel_searches
         executed_bytes_launch = alg0_bytes_launch * (
             (main_searches / world) / full_searches)
         achieved = executed_bytes_launch / (kms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes of the dominant kernel from the PMC passes of this very
+        # kernel source (scripts/pmc_passes.sh writes the file; a profile of
+        # other sources is not quoted)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if (tj.get("index_bp") == n and tj.get("queries") == nq):
+            if (tj.get("index_bp") == n and tj.get("queries") == nq and
+                    tj.get("kernel_source_sha16") == kernel_source_hash()):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = tj.get("source")
         out["roofline"] = {
             "kernel": "k_query_search<uint32_t, MUM, deep, 256>",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel_ms": kms,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel_ms": kms,
             "algorithmic_bytes_per_launch": executed_bytes_launch,
             "searches_per_launch": main_searches / world,
             "algorithmic_bytes_per_query_all_suffixes": bytes_per_query,
             "achieved_if_priced_on_all_suffixes":
                 alg0_bytes_launch / (kms * 1e-3) / 1e9,
-            "note": "algorithmic bytes = SURVEY 8d formula counted by the "
-                    "instrumented CPU restatement (7.1 kB per 100 bp query "
+            "bytes_are": "modelled",
+            "note": "kernel_ms: HIP events around the kernel, this run. "
+                    "algorithmic bytes = SURVEY 8d formula counted by the "
+                    "instrumented CPU restatement (%.1f kB per 100 bp query "
                     "for all 81 suffixes) scaled to the %.1f%% of the "
                     "suffix searches this kernel executes after the first "
                     "pass and the work plan; the path is random 8/16-byte "
-                    "reads, one 64-byte sector each (traffic/algorithmic "
-                    "~ %.2f), see DESIGN.md"
-                    % (100.0 * main_searches / world / full_searches,
-                       (traffic or 0) / executed_bytes_launch)}
+                    "reads, one 64-byte sector each, see DESIGN.md"
+                    % (bytes_per_query / 1e3,
+                       100.0 * main_searches / world / full_searches)}
+        fams = []
+        if world == 1:
+            # every query once, with the whole query: priced like the
+            # reference's complete-match search of a query (exactcompl.c:168)
+            cbytes, _ = count_bytes(
+                H, lambda: H.oracle_complete(host, small), small.nq, w,
+                int(small.length.sum()))
+            fams.append(family(
+                "k_mum_first<uint32_t, deep>", "-mum -l %d, first pass" % L,
+                fms, cbytes * nq,
+                "offset 0 of every query located with the whole query; "
+                "bytes = %.0f B/query, the reference's -complete search of "
+                "the query (bucket, binary search, comparison, lcp)" % cbytes,
+                queries=nq))
+        if extras:
+            fams += extra_families(a, V, H, index, queries, q150, host, small,
+                                   w, nq, m, L, bytes_per_query, cbytes)
+        out["roofline_families"] = fams
         if world == 1 and a.cpu_sample > 0:
-            host.sti1 = index.make_sti1()
-            sample = H.Queries.uniform(qsym[:a.cpu_sample * m], m)
-            t0 = time.perf_counter()
-            ref = H.oracle_querymatches(host, sample, L, mum=True, speedup=2)
-            dt = time.perf_counter() - t0
-            # the same sample as a batch of its own on the GPU: identical list
-            gsample = V.Queries.from_host(sample.symbols, sample.start,
-                                          sample.length, dev)
-            gres = V.findquerymatches(index, gsample, L, mum=True)
-            same = bool(np.array_equal(gres.fetch(), ref))
-            gres.close()
-            if not same:
-                raise RuntimeError("bench.py: GPU and CPU oracle disagree on "
-                                   "the %d-query sample" % sample.nq)
-            out["cpu_baseline"] = {
-                "value": sample.nq / dt, "unit": "queries/s", "cores": 1,
-                "kind": "port",
-                "sample": "first %d queries of the same batch, same 3 Gbp "
-                          "index (32-bit tables), oracle/vsoracle.c "
-                          "algorithm 2 = the reference's default -qspeedup 2 "
-                          "incl. the MUM filter, %.1f s, %d MUMs"
-                          % (sample.nq, dt, len(ref)),
-                "gpu_list_equal_on_sample": same}
-            # the real reference program, timed once on a GPU box on the
-            # same index and sample size (scripts/cpu_reference_probe.py)
-            rpath = os.path.join(ROOT, "profiles", "cpu_reference.json")
-            if os.path.exists(rpath) and n == 3000000000 and m == 100:
-                with open(rpath) as f:
-                    rj = json.load(f)
-                run = rj["runs"].get("-mum -l %d" % L)
-                if run:
-                    out["cpu_baseline"]["reference_vmatch"] = {
-                        "value": run["queries_per_s"], "unit": "queries/s",
-                        "cores": 1, "kind": "reference",
-                        "sample": "%d queries, %s" % (rj["queries"],
-                                                      rj["source"])}
-            out["speedup_vs_cpu_1core"] = qps / (sample.nq / dt)
+            out["cpu_baseline"] = cpu_baselines(
+                a, V, H, index, host, qsym, m, L, dev, qps,
+                free_index=lambda: index.close())
+        if extras:
+            fams.append(selfmum_family(a, V, n, L, dev))
+        sys.stdout.flush()
+        os.write(jsonfd, (json.dumps(out) + "\n").encode())
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
+                   bytes_per_query, cbytes):
+    """the other kernel families of the path on the same index: a few calls
+    each, HIP-event kernel times from the library's statistics"""
+    fams = []
+
+    def best(fn, reps=4):
+        got = []
+        for _ in range(reps):
+            r = fn()
+            got.append(r.stats())
+            r.close()
+        return min(got, key=lambda s: s.total_device_ms)
+
+    s = best(lambda: V.findcompletematches(index, queries))
+    fams.append(family(
+        "k_complete_search<uint32_t, deep>", "-complete (BASELINE configs[1] "
+        "semantics on the 3 Gbp index)", s.search_kernel_ms, cbytes * nq,
+        "bytes = %.0f B/query (SURVEY 8d: m + 2w + probes*(w + c) + lcp + "
+        "occ*(w + 16))" % cbytes, queries=nq, matches=s.count,
+        call_device_ms=s.total_device_ms))
+    s = best(lambda: V.findquerymatches(index, queries, L), reps=2)
+    fams.append(family(
+        "k_query_search<uint32_t, MEM, deep, 256>", "-l %d (MEM)" % L,
+        s.search_kernel_ms, bytes_per_query * nq,
+        "all %d suffixes of every query are searched; bytes = %.0f B/query"
+        % (m - L + 1, bytes_per_query), queries=nq, matches=s.count,
+        call_device_ms=s.total_device_ms))
+    # BASELINE configs[4]: -complete -e 2 on 150 bp reads
+    s = best(lambda: V.findapproxcompletematches(index, q150, True, 2), reps=3)
+    # piece search: every read is cut into exact pieces (splitesaapm.c:317),
+    # each searched like a complete match; counted on a sample of 30-mers
+    piece = H.Queries.uniform(np.ascontiguousarray(
+        small.symbols.reshape(small.nq, m)[:, :30]).ravel(), 30)
+    pbytes, _ = count_bytes(H, lambda: H.oracle_complete(host, piece),
+                            piece.nq, w, int(piece.length.sum()))
+    fams.append(family(
+        "k_complete_search<uint32_t, deep> (pieces)",
+        "-complete -e 2, 10 M x 150 bp (BASELINE configs[4]): piece search",
+        s.search_kernel_ms, pbytes * s.searches,
+        "%d pieces of 30 bp, %.0f B each" % (s.searches, pbytes),
+        queries=nq, matches=s.count, call_device_ms=s.total_device_ms))
+    band = 150 + 2 * 2 + 150   # text window + pattern per start position
+    fams.append(family(
+        "k_apm_banded<2>",
+        "-complete -e 2, 10 M x 150 bp: banded alignment of the start "
+        "positions", s.first_kernel_ms, float(band) * s.kernel_searches,
+        "%d start positions x (154 text + 150 pattern symbols)"
+        % s.kernel_searches, queries=nq))
+    return fams
+
+
+def selfmum_family(a, V, n, L, dev):
+    """K3, the suftab/lcptab scan: an index of its own (database + separator +
+    diverged copy as query part), built after the query index is gone"""
+    tis, half = selfmum_text(V, n)
+    t0 = time.time()
+    idx = V.Index.build(tis, 4, 0, dev)
+    idx.set_queryseparator(half)
+    log("self-index text %d bp built in %.1fs" % (len(tis), time.time() - t0))
+    got = []
+    for _ in range(5):
+        r = V.findmaximaluniquematches(idx, L)
+        got.append(r.stats())
+        r.close()
+    s = min(got[1:], key=lambda x: x.search_kernel_ms)
+    idx.close()
+    return family(
+        "k_selfmum_peaks<4, nontemporal>",
+        "-mum -l %d on an index that holds its queries (the suftab scan, "
+        "fmumself.c)" % L, s.search_kernel_ms, 2.0 * (len(tis) + 1),
+        "streams lcptab and bwttab once: 2(n+1) bytes; the whole call "
+        "(peaks -> suf gathers -> MUM list) %.2f ms, %d MUMs"
+        % (s.total_device_ms, s.count), matches=s.count,
+        call_device_ms=s.total_device_ms)
+
+
+def cpu_baselines(a, V, H, index, host, qsym, m, L, dev, qps, free_index):
+    ns = min(a.cpu_sample, len(qsym) // m)
+    host.sti1 = H.sti1_from_tables(host.suf, host.lcp, host.prefixlength)
+    sample = H.Queries.uniform(qsym[:ns * m], m)
+    t0 = time.perf_counter()
+    ref = H.oracle_querymatches(host, sample, L, mum=True, speedup=2)
+    dt = time.perf_counter() - t0
+    # the same sample as a batch of its own on the GPU: identical list
+    gsample = V.Queries.from_host(sample.symbols, sample.start, sample.length,
+                                  dev)
+    gres = V.findquerymatches(index, gsample, L, mum=True)
+    same = bool(np.array_equal(gres.fetch(), ref))
+    gres.close()
+    gsample.close()
+    if not same:
+        raise RuntimeError("bench.py: GPU and CPU oracle disagree on the "
+                           "%d-query sample" % sample.nq)
+    port = {"value": sample.nq / dt, "unit": "queries/s", "cores": 1,
+            "kind": "port",
+            "sample": "first %d queries of the same batch, same index "
+                      "(32-bit tables), oracle/vsoracle.c algorithm 2 = the "
+                      "reference's default -qspeedup 2 incl. the MUM filter, "
+                      "engine only (no FASTA parsing, no output), %.1f s, %d "
+                      "MUMs" % (sample.nq, dt, len(ref)),
+            "gpu_list_equal_on_sample": same}
+    # P: the host cores that go with one GPU of the box (gpurun: 16 per GPU;
+    # the machine shows all its hardware threads to every box)
+    ncores = min(len(os.sched_getaffinity(0)),
+                 int(os.environ.get("VSA_BENCH_CORES", "16")))
+    refb = None
+    if not a.quick:
+        genome = host.tis
+        free_index()      # vsa_mkvtree builds its own copy on the GPU
+        try:
+            refb = reference_baseline(a, V, H, genome, qsym, m, L, ncores)
+        except Exception as e:          # the baseline must not sink the line
+            log("reference baseline failed: %r" % (e,))
+        if refb is not None and refb["mums_1core_sample"] != len(ref):
+            raise RuntimeError("bench.py: vmatch_ref reports %d MUMs on the "
+                               "sample, GPU and port %d"
+                               % (refb["mums_1core_sample"], len(ref)))
+    if refb is None:
+        port["speedup_gpu_vs_this"] = qps / port["value"]
+        return port
+    refb["port_1core"] = port
+    refb["gpu_over_reference_all_cores"] = qps / refb["value"]
+    refb["gpu_over_reference_1core"] = qps / refb["reference_1core"]["value"]
+    return refb
+
+
+def selfmum_mode(a, V, S, torch, dist, rank, world, dev, jsonfd):
+    """SURVEY 8e, third row: the self-index scan split into suffix-array
+    ranges.  Every rank holds the whole index and scans its range (the entries
+    around the range's ends come from its own replica); the lists stay
+    distributed in suffix-array order; one all-reduce sums the counters.
+    Strong scaling: the text is fixed, the ranges shrink with N."""
+    from vstree_amd import sharding as Sh
+    n, L = int(a.genome), a.minlen
+    tis, half = selfmum_text(V, n)
+    t0 = time.time()
+    idx = V.Index.build(tis, 4, 0, dev)
+    idx.set_queryseparator(half)
+    t_index = time.time() - t0
+    first, last = Sh.selfmum_range(len(tis), rank, world)
+    distributed = world > 1 or a.force_distributed
+    totals = None
+
+    def sync():
+        V.device_synchronize(dev)
+        if distributed:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kms = []
+
+    def one_step():
+        nonlocal totals
+        r = V.findmaximaluniquematches(idx, L, first, last)
+        s = r.stats()
+        kms.append(s.search_kernel_ms)
+        totals = [s.count, s.sumlength]
+        r.close()
+        if distributed:
+            totals = Sh.all_reduce_counters(
+                dist, torch, totals,
+                "cpu" if a.rehearse_on_one_gpu else "cuda")
+
+    for _ in range(a.warmup):
+        one_step()
+    kms.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        e = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if a.rehearse_on_one_gpu else "cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+    if rank == 0:
+        ms = float(np.mean(kms))
+        nbytes = 2.0 * (last - first)
+        out = {
+            "metric": "suffix-array positions scanned per second (vmatch -mum "
+                      "-l 20 on an index that holds its queries, 3 Gbp)",
+            "value": len(tis) * a.steps / elapsed, "unit": "positions/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "self-index MUM scan (fmumself.c), %d bp "
+                                   "text = database + separator + diverged "
+                                   "copy, -l %d, suffix-array ranges x%d"
+                                   % (len(tis), L, world),
+                       "index_build_s": round(t_index, 2)},
+            "matches": totals[0],
+            "roofline": family("k_selfmum_peaks<4, nontemporal>",
+                               "rank 0's range", ms, nbytes,
+                               "lcptab + bwttab of the range, once")}
         sys.stdout.flush()
         os.write(jsonfd, (json.dumps(out) + "\n").encode())
     if distributed:

@@ -212,6 +212,9 @@ typedef struct
   double total_device_ms;  /* HIP-event time of the whole call            */
   double anchor_ms;        /* -mum: anchor pass + work list (0 if unused)  */
   uint64_t kernel_searches; /* of those: by the dominant search kernel     */
+  double first_kernel_ms;  /* -mum: HIP-event time of the first pass kernel
+                              (offset 0 of every query, whole query);
+                              -complete -e/-h: of the banded alignment     */
 } vsa_stats;
 
 uint64_t vsa_result_count(const vsa_result *result);

@@ -11,7 +11,7 @@ mkdir -p $R/gpurun_out/$OUT
 i=0
 for line in "$@"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $line --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $R/gpurun_out/$OUT/p$i.json 2> $R/gpurun_out/$OUT/p$i.err
+  timeout -k 10 150 rocprofv3 --pmc $line --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --quick > $R/gpurun_out/$OUT/p$i.json 2> $R/gpurun_out/$OUT/p$i.err
   echo "pass $i rc=$? : $line" >> $R/gpurun_out/$OUT/progress.log
 done
 cat $R/gpurun_out/$OUT/progress.log

@@ -7,8 +7,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 
 
 def short(name):
@@ -58,7 +62,8 @@ def main():
                          "FETCH_SIZE x 1024 (one 64-byte request per L2 "
                          "miss); the x2 correction of MI355X_MICROARCH.md "
                          "for wide coalesced streams is not applied",
-                 "round": 1, "source": out}
+                 "kernel_source_sha16": kernel_source_hash(),
+                 "round": 2, "source": out}
             json.dump(j, open(traffic, "w"), indent=1)
             print(json.dumps(j))
 

@@ -82,7 +82,8 @@ class Stats(C.Structure):
                 ("searches", C.c_uint64), ("candidates", C.c_uint64),
                 ("search_kernel_ms", C.c_double),
                 ("total_device_ms", C.c_double), ("anchor_ms", C.c_double),
-                ("kernel_searches", C.c_uint64)]
+                ("kernel_searches", C.c_uint64),
+                ("first_kernel_ms", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -948,6 +948,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
+  Timer tfirst(stream); // the first pass kernel (k_mum_first) alone
   // ragged batches take the same route with per-query geometry
   const uint64_t maxoffsets =
       (queries->maxlength >= searchlength)
@@ -992,6 +993,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       {
         return -100;
       }
+      tfirst.start();
       if (deepok)
       {
         if constexpr (sizeof(IDX) == 4)
@@ -1008,6 +1010,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
             wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
             wfmdb.as<uint64_t>());
       }
+      tfirst.stop();
     } else if (deepok)
     {
       if constexpr (sizeof(IDX) == 4)
@@ -1460,6 +1463,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   res->stats.count = res->count;
   res->stats.search_kernel_ms = searchms;
   res->stats.anchor_ms = anchorms;
+  res->stats.first_kernel_ms = tfirst.ms();
   res->stats.kernel_searches = nwork;
   res->stats.total_device_ms = tall.ms();
   if (mumsum != ~0ull)
