@@ -108,12 +108,37 @@ def count_bytes(H, run, nq, w, symbols):
     return total / nq, c
 
 
-def family(name, mode, ms, nbytes, note, **more):
+_TRAFFIC = None
+
+
+def pmc_traffic(n, nq):
+    """HBM bytes per launch from the committed PMC passes (scripts/
+    pmc_passes.sh + pmc_summary.py), quoted only if they were taken at this
+    size with these very kernel sources -- a profile of other sources says
+    nothing about this run"""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        _TRAFFIC = {}
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if (tj.get("index_bp") == n and tj.get("queries") == nq and
+                    tj.get("kernel_source_sha16") == kernel_source_hash()):
+                _TRAFFIC = tj
+    return _TRAFFIC
+
+
+def family(name, mode, ms, nbytes, note, traffic_key=None, **more):
     ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     d = {"kernel": name, "mode": mode, "bound": "hbm", "achieved": ach,
          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
          "traffic": None, "kernel_ms": ms,
          "algorithmic_bytes_per_launch": nbytes, "note": note}
+    fam = (_TRAFFIC or {}).get("families", {}).get(traffic_key)
+    if fam:
+        d["traffic"] = fam["hbm_bytes_per_launch"]
+        d["traffic_source"] = _TRAFFIC.get("source")
     d.update(more)
     return d
 
@@ -452,15 +477,9 @@ def main():
         # HBM bytes of the dominant kernel from the PMC passes of this very
         # kernel source (scripts/pmc_passes.sh writes the file; a profile of
         # other sources is not quoted)
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if (tj.get("index_bp") == n and tj.get("queries") == nq and
-                    tj.get("kernel_source_sha16") == kernel_source_hash()):
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = tj.get("source")
+        tj = pmc_traffic(n, nq)
+        traffic, traffic_source = (tj.get("hbm_bytes_per_launch"),
+                                   tj.get("source"))
         out["roofline"] = {
             "kernel": "k_query_search<uint32_t, MUM, deep, 256>",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -495,7 +514,7 @@ def main():
                 "offset 0 of every query located with the whole query; "
                 "bytes = %.0f B/query, the reference's -complete search of "
                 "the query (bucket, binary search, comparison, lcp)" % cbytes,
-                queries=nq))
+                traffic_key="k_mum_first", queries=nq))
         if extras:
             fams += extra_families(a, V, H, index, queries, q150, host, small,
                                    w, nq, m, L, bytes_per_query, cbytes)
@@ -532,15 +551,15 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
         "k_complete_search<uint32_t, deep>", "-complete (BASELINE configs[1] "
         "semantics on the 3 Gbp index)", s.search_kernel_ms, cbytes * nq,
         "bytes = %.0f B/query (SURVEY 8d: m + 2w + probes*(w + c) + lcp + "
-        "occ*(w + 16))" % cbytes, queries=nq, matches=s.count,
-        call_device_ms=s.total_device_ms))
+        "occ*(w + 16))" % cbytes, traffic_key="k_complete_search", queries=nq,
+        matches=s.count, call_device_ms=s.total_device_ms))
     s = best(lambda: V.findquerymatches(index, queries, L), reps=2)
     fams.append(family(
         "k_query_search<uint32_t, MEM, deep, 256>", "-l %d (MEM)" % L,
         s.search_kernel_ms, bytes_per_query * nq,
         "all %d suffixes of every query are searched; bytes = %.0f B/query"
-        % (m - L + 1, bytes_per_query), queries=nq, matches=s.count,
-        call_device_ms=s.total_device_ms))
+        % (m - L + 1, bytes_per_query), traffic_key="k_query_search_mem",
+        queries=nq, matches=s.count, call_device_ms=s.total_device_ms))
     # BASELINE configs[4]: -complete -e 2 on 150 bp reads
     s = best(lambda: V.findapproxcompletematches(index, q150, True, 2), reps=3)
     # piece search: every read is cut into exact pieces (splitesaapm.c:317),
@@ -561,7 +580,7 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
         "-complete -e 2, 10 M x 150 bp: banded alignment of the start "
         "positions", s.first_kernel_ms, float(band) * s.kernel_searches,
         "%d start positions x (154 text + 150 pattern symbols)"
-        % s.kernel_searches, queries=nq))
+        % s.kernel_searches, traffic_key="k_apm_banded", queries=nq))
     return fams
 
 
@@ -586,8 +605,8 @@ def selfmum_family(a, V, n, L, dev):
         "fmumself.c)" % L, s.search_kernel_ms, 2.0 * (len(tis) + 1),
         "streams lcptab and bwttab once: 2(n+1) bytes; the whole call "
         "(peaks -> suf gathers -> MUM list) %.2f ms, %d MUMs"
-        % (s.total_device_ms, s.count), matches=s.count,
-        call_device_ms=s.total_device_ms)
+        % (s.total_device_ms, s.count), traffic_key="k_selfmum_peaks",
+        matches=s.count, call_device_ms=s.total_device_ms)
 
 
 def cpu_baselines(a, V, H, index, host, qsym, m, L, dev, qps, free_index):

@@ -84,6 +84,12 @@ int vsa_index_open(const char *indexname, int device, vsa_index **index);
 
 void vsa_index_close(vsa_index *index);
 
+/* A replica of an index on another HIP device of the node (or on the same
+   one): every table, the derived search tables included, is copied device to
+   device -- over xGMI between two GPUs -- and nothing is built again.  The
+   multi-GPU entry points (include/vstree_amd_multi.h) replicate with it. */
+int vsa_index_clone(const vsa_index *index, int device, vsa_index **clone);
+
 typedef struct
 {
   uint64_t totallength, numofcodes, largelcpvalues, device_bytes;

@@ -1,0 +1,92 @@
+/*
+  vstree_amd_multi.h -- the query path on all GPUs of one node, C ABI.
+
+  One process, one host thread per GPU.  The index is replicated in every
+  GPU's HBM (uploaded once per device in parallel from the host tables, or
+  copied device to device from a replica that exists already); the queries of
+  a call are cut into contiguous blocks, one per GPU, and keep their global
+  numbers (Vmengine/fquery.c:1010 `onlinequerynumoffset`).  SURVEY.md 8e:
+
+    -complete, -l (MEM), -mum cand   every query is independent
+        (Vmengine/fcomplete.c:313-319, Vmengine/fquery.c:468-475): no exchange;
+        the lists of the GPUs concatenated in block order are the reference's
+        list.
+    -mum                             the candidates of ALL queries pass one
+        filter (kurtz/cleanMUMcand.c:55-118): each GPU groups its candidates
+        by the range of the index their dbstart falls into, range r goes to GPU
+        r (peer copies over xGMI), GPU r filters its range given the largest
+        right end of the ranges before it; the lists concatenated in GPU order
+        are the reference's list (ascending dbstart).
+    match counters                   one RCCL all-reduce (sum) over the GPUs.
+
+  What a caller of the reference's engine binds instead of
+  findcompletematches / findquerymatches (Vmengine/vmengineexport.h:4-81) when
+  it wants all GPUs: integration/vmengine_shim.c does so for VMATCH_GPUS > 1.
+  Library: vstree_amd/libvstree_amd_multi.so (needs libvstree_amd.so, librccl).
+*/
+#ifndef VSTREE_AMD_MULTI_H
+#define VSTREE_AMD_MULTI_H
+
+#include "vstree_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsa_multi vsa_multi;
+
+/* the host tables uploaded to every device of the list, all at the same time
+   (one PCIe link per GPU); a device may be named twice (two replicas on one
+   GPU: how the tests run on a one-GPU box) */
+int vsa_multi_from_tables(const vsa_tables *tables, const int *devices,
+                          uint32_t ndevices, vsa_multi **multi);
+
+/* replicas of an index that lives on a device already (built there by
+   vsa_index_build / opened by vsa_index_open): vsa_index_clone to every other
+   entry of the list.  `first` becomes replica 0 and belongs to the set from
+   now on (vsa_multi_close closes it); devices[0] must be its device. */
+int vsa_multi_replicate(vsa_index *first, const int *devices,
+                        uint32_t ndevices, vsa_multi **multi);
+
+uint32_t vsa_multi_ndevices(const vsa_multi *multi);
+vsa_index *vsa_multi_index(vsa_multi *multi, uint32_t replica);
+void vsa_multi_close(vsa_multi *multi);
+
+/* 1 if the counters of the last call were summed by RCCL (distinct devices,
+   communicators initialised), 0 if on the host (replicas sharing a device) */
+int vsa_multi_uses_rccl(const vsa_multi *multi);
+
+#define VSA_MULTI_COMPLETE 0 /* vmatch -complete            findcompletematches */
+#define VSA_MULTI_MEM      1 /* vmatch -l L                 findquerymatches    */
+#define VSA_MULTI_MUMCAND  2 /* vmatch -mum cand -l L       findquerymatches    */
+#define VSA_MULTI_MUM      3 /* vmatch -mum -l L            findquerymatches    */
+
+/*
+  One engine call over all replicas.  Queries as for vsa_queries_from_host
+  (symbols / start / length of a Multiseq, host memory).  The matches come
+  back in host memory (free with vsa_multi_free_matches), in the reference's
+  order; total = the counters of the whole job (count, sumlength, searches,
+  candidates).  Errors as in the single-GPU calls, incl. the reference's
+  "patternlength=... must be >= ...=prefixlen" with the matches of the
+  queries before the offending one.
+*/
+int vsa_multi_findmatches(vsa_multi *multi, int mode, uint64_t searchlength,
+                          const uint8_t *symbols, uint64_t nsymbols,
+                          const uint64_t *start, const uint64_t *length,
+                          uint64_t nq, vsa_match **matches, uint64_t *count,
+                          vsa_stats *total);
+void vsa_multi_free_matches(vsa_match *matches);
+
+/* the same with the reference's delivery model: callbacks on the calling
+   thread, in reference order, stop on a non-zero return */
+int vsa_multi_findmatches_cb(vsa_multi *multi, int mode,
+                             uint64_t searchlength, const uint8_t *symbols,
+                             uint64_t nsymbols, const uint64_t *start,
+                             const uint64_t *length, uint64_t nq,
+                             vsa_processmatch processmatch, void *info);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

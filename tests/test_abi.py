@@ -36,6 +36,23 @@ def test_library_exports_every_declared_symbol(V):
     assert sorted(V.ABI_SYMBOLS) == syms
 
 
+def test_multi_gpu_library_exports_its_header(V):
+    """include/vstree_amd_multi.h <-> libvstree_amd_multi.so (symbol table
+    only: loading it needs RCCL and a HIP runtime with a device)"""
+    text = open(os.path.join(H.ROOT, "include", "vstree_amd_multi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(vsa_multi_[a-z0-9_]+)\s*\(", text)))
+    assert len(syms) >= 9
+    path = os.path.join(os.path.dirname(V.LIBPATH), "libvstree_amd_multi.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only",
+                                   path]).decode()
+    have = {l.split()[-1] for l in out.splitlines() if l}
+    assert set(syms) <= have
+    # no kernels of its own, and it needs the product library
+    need = subprocess.check_output(["readelf", "-d", path]).decode()
+    assert "libvstree_amd.so" in need and "librccl" in need
+
+
 def test_synthetic_generator_matches_recorded_md5(V):
     m = H.manifest()["c1"]
     g, q, n, nq, mm = H.synth_c1()

@@ -158,3 +158,154 @@ def test_planted_answers_and_global_mum_filter(V, world):
         assert np.array_equal(tis[s:s + ln], hq[qo:qo + ln])
         assert qo + ln == M or s + ln == N or tis[s + ln] != hq[qo + ln]
         assert qo == 0 or s == 0 or tis[s - 1] != hq[qo - 1]
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[1]: 200 Mbp index, 1 M x 100 bp, -complete -- small
+# enough for the CPU oracle to answer EVERY query: the whole list, in order.
+# ---------------------------------------------------------------------------
+
+N2 = int(float(os.environ.get("VSA_CONFIG1_BP", "2e8")))
+NQ2 = int(float(os.environ.get("VSA_CONFIG1_QUERIES", "1e6")))
+
+
+def test_config1_complete_matches_of_all_queries_equal_the_oracle(V):
+    dg = V.device_malloc(N2 + 64)
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, N2, dg, 0))
+    index = V.Index.build_device(dg, N2, 4, 0)
+    pos, sub, step = V.synth_query_plan(N2, NQ2, M)
+    dq = V.device_malloc(NQ2 * M + 64)
+    V._check(V.lib.vsa_synth_queries_device(dg, N2, pos.ctypes.data,
+                                            sub.ctypes.data, step.ctypes.data,
+                                            NQ2, M, dq, 0))
+    queries = V.Queries.from_device(dq, NQ2, M)
+    V.device_free(dq)
+    V.device_free(dg)
+    t = index.download()
+    info = index.info()
+    assert info.prefixlength == H.recommended_prefixlength(4, N2) == 11
+    host = H.Index(N2, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
+                   t["llv"], t["bck"], t["bwt"], None)
+    hq = host_queries(dict(host=host, pos=pos, sub=sub, step=step),
+                      np.arange(NQ2))
+    got = V.findcompletematches(index, queries).fetch()
+    want = H.oracle_complete(host, hq)
+    assert len(want) >= NQ2 * 7 // 10          # ~75 % of the reads are exact
+    assert np.array_equal(got, want)
+    # and the query path on the same index, against the oracle on a sample
+    sel = np.arange(0, NQ2, max(1, NQ2 // 20000))[:20000]
+    hs = host_queries(dict(host=host, pos=pos, sub=sub, step=step), sel)
+    gs = V.Queries.from_host(hs.symbols, hs.start, hs.length)
+    host.sti1 = H.sti1_from_tables(host.suf, host.lcp, host.prefixlength)
+    for kw, sp in (({}, 2), (dict(mum=True), 2)):
+        assert np.array_equal(
+            V.findquerymatches(index, gs, L, speedup=sp, **kw).fetch(),
+            H.oracle_querymatches(host, hs, L, speedup=sp, **kw)), kw
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[4]: 3 Gbp index, 10 M x 150 bp, -complete -e 2.
+#   * CPU oracle (restatement of approxcompl.c / splitesaapm.c, pinned against
+#     the reference) on a sample of >= 3 000 reads: identical lists, in order;
+#   * the planted answers of the generator: every read must be reported at the
+#     position it was cut from, over its whole length, at the distance the
+#     generator gave it (0 or 1 substitution);
+#   * every reported match is within 2 errors: unit-cost edit distance of the
+#     read and the reported piece of the text, recomputed with numpy for a
+#     large random sample of the ~45 M matches, must equal the reported one.
+# ---------------------------------------------------------------------------
+
+M5, K5 = 150, 2
+NQ5 = int(float(os.environ.get("VSA_CONFIG4_QUERIES", os.environ.get(
+    "VSA_FULLSCALE_QUERIES", "1e7"))))
+
+
+def edit_distances(a, b, la, lb):
+    """unit-cost edit distance of a[i,:la[i]] and b[i,:lb[i]] for all rows
+    (plain dynamic programming, one numpy row operation per cell column)"""
+    rows, wa = a.shape
+    wb = b.shape[1]
+    inf = np.int32(1 << 20)
+    prev = np.tile(np.arange(wb + 1, dtype=np.int32), (rows, 1))
+    out = prev[np.arange(rows), lb].copy()
+    out[la != 0] = inf
+    for i in range(1, wa + 1):
+        cur = np.empty_like(prev)
+        cur[:, 0] = i
+        sub_ = prev[:, :-1] + (a[:, i - 1:i] != b)
+        dele = prev[:, 1:] + 1
+        best = np.minimum(sub_, dele)
+        # insertions: running minimum along the row
+        cur[:, 1:] = best
+        for j in range(1, wb + 1):
+            np.minimum(cur[:, j], cur[:, j - 1] + 1, out=cur[:, j])
+        done = la == i
+        out[done] = cur[done, lb[done]]
+        prev = cur
+    return out
+
+
+def test_config4_approximate_matches_at_full_size(V, world):
+    ix, host = world["index"], world["host"]
+    dg = V.device_malloc(N + 64)
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, N, dg, 0))
+    pos, sub, step = V.synth_query_plan(N, NQ5, M5)
+    dq = V.device_malloc(NQ5 * M5 + 64)
+    V._check(V.lib.vsa_synth_queries_device(dg, N, pos.ctypes.data,
+                                            sub.ctypes.data, step.ctypes.data,
+                                            NQ5, M5, dq, 0))
+    queries = V.Queries.from_device(dq, NQ5, M5)
+    V.device_free(dq)
+    V.device_free(dg)
+    res = V.findapproxcompletematches(ix, queries, True, K5)
+    m = res.fetch()
+    res.close()
+    g = host.tis
+    dist = m["querystart"]                  # the distance travels here
+    qn = m["queryseq"].astype(np.int64)
+    assert (dist <= K5).all() and len(m) >= NQ5
+    assert (np.diff(qn) >= 0).all()         # reads in order
+
+    def reads(sel):
+        out = g[pos[sel, None].astype(np.int64) + np.arange(M5)[None, :]]
+        hit = np.flatnonzero(sub[sel] != 0xFFFFFFFF)
+        c = sub[sel][hit]
+        out[hit, c] = (out[hit, c] + step[sel][hit]) & 3
+        return out
+
+    # 1. the oracle on a sample, lists in order
+    sel = np.arange(0, NQ5, max(1, NQ5 // 3000))[:3000]
+    hq = H.Queries.uniform(reads(sel).ravel(), M5)
+    gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
+    got = V.findapproxcompletematches(ix, gq, True, K5).fetch()
+    want = H.oracle_approx(host, hq, True, K5)
+    assert len(want) >= 3000
+    assert np.array_equal(got, want)
+    # ... and the same reads inside the big batch gave the same matches
+    inbig = m[np.isin(qn, sel)].copy()
+    inbig["queryseq"] = np.searchsorted(sel, inbig["queryseq"])
+    assert np.array_equal(inbig, want)
+    # 2. planted answers: every read is reported from the position it was cut
+    # at, with the generator's distance (0, or 1 substitution) -- over its
+    # whole length if exact; with one substitution the longest match of that
+    # distance may be a symbol shorter or longer (a substituted last symbol
+    # can also be read as a deletion or an insertion, longestmatch.c:18-71)
+    wantdist = (sub != 0xFFFFFFFF).astype(np.uint64)
+    planted = ((m["dbstart"] == pos[qn]) & (dist == wantdist[qn]) &
+               (np.abs(m["length"].astype(np.int64) - M5) <= wantdist[qn]))
+    seen = np.zeros(NQ5, bool)
+    seen[qn[planted]] = True
+    assert seen.all()
+    # from one start position only one match is reported
+    key = qn * (N + 1) + m["dbstart"].astype(np.int64)
+    assert len(np.unique(key)) == len(key)
+    # 3. reported distance == recomputed edit distance, random sample
+    rng = np.random.default_rng(11)
+    pick = rng.integers(0, len(m), size=200000)
+    a = reads(qn[pick])
+    ln = m["length"][pick].astype(np.int64)
+    assert (ln >= M5 - K5).all() and (ln <= M5 + K5).all()
+    b = g[np.minimum(m["dbstart"][pick, None].astype(np.int64) +
+                     np.arange(M5 + K5)[None, :], N - 1)]
+    d = edit_distances(a, b, np.full(len(pick), M5), ln)
+    assert np.array_equal(d.astype(np.uint64), dist[pick])

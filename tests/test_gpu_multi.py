@@ -1,0 +1,129 @@
+"""The C multi-GPU entry points (include/vstree_amd_multi.h) on a one-GPU box:
+several replicas of the index on device 0, one host thread each.  What is
+under test is everything but the wire: the block split with global query
+numbers, the concatenation in reference order, the range-partitioned MUM
+filter with peer copies and carries -- all through the real GPU kernels
+(vsa_result_partition -> exchange -> range filter), compared with the golden
+lists of the single-process reference."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def MG(V):
+    from vstree_amd import multi
+    return multi
+
+
+def tables(MG, case, devices):
+    idx, q = H.load_case(case)
+    i = idx.as_width(64)
+    return idx, q, MG.Multi.from_tables(i.n, i.prefixlength, i.numofchars,
+                                        i.tis, i.suf, i.lcp, i.llv, i.bck,
+                                        i.bwt, devices=devices)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_replicas_reproduce_the_reference_lists(V, MG, world):
+    idx, q, m = tables(MG, "c1", [0] * world)
+    assert m.ndevices() == world
+    for mode, key, L in ((MG.COMPLETE, "complete", 0),
+                         (MG.MUMCAND, "mumcand20", 20), (MG.MUM, "mum20", 20),
+                         (MG.MEM, "mem20_sp2", 20)):
+        got, st, rc, msg = m.findmatches(mode, q.symbols, q.start, q.length, L)
+        assert rc == 0, msg
+        want = H.expected("c1", key)
+        assert np.array_equal(H.matches_as_ref(idx, got), want), (world, key)
+        assert st.count == len(want)
+        assert st.sumlength == int(want["length"].sum())
+        if mode == MG.MUM:
+            assert st.candidates == len(H.expected("c1", "mumcand20"))
+    # counters of replicas that share a device are summed on the host
+    assert m.uses_rccl() == (world == 1)
+    m.set_queryspeedup(0)
+    got, _, rc, _ = m.findmatches(MG.MEM, q.symbols, q.start, q.length, 20)
+    assert np.array_equal(H.matches_as_ref(idx, got),
+                          H.expected("c1", "mem20_sp0"))
+    m.close()
+
+
+def test_one_replica_sums_its_counters_through_rccl(V, MG):
+    """a communicator of one rank: the ncclAllReduce path runs for real"""
+    idx, q, m = tables(MG, "micro", [0])
+    got, st, rc, msg = m.findmatches(MG.COMPLETE, q.symbols, q.start,
+                                     q.length)
+    assert rc == 0, msg
+    assert m.uses_rccl()
+    want = H.oracle_complete(idx, q)
+    assert np.array_equal(got, want) and st.count == len(want)
+    m.close()
+
+
+def test_repetitive_text_ragged_queries_and_wildcards(V, MG):
+    idx, q, m = tables(MG, "largepat", [0, 0, 0])
+    pl = idx.prefixlength
+    for mode, kw in ((MG.MEM, {}), (MG.MUMCAND, dict(mum=True, cand=True)),
+                     (MG.MUM, dict(mum=True))):
+        got, st, rc, msg = m.findmatches(mode, q.symbols, q.start, q.length,
+                                         pl + 6)
+        assert rc == 0, msg
+        assert np.array_equal(
+            got, H.oracle_querymatches(idx, q, pl + 6, speedup=2, **kw)), mode
+    m.close()
+    idx, q, m = tables(MG, "wildcards", [0, 0])
+    got, _, rc, _ = m.findmatches(MG.MEM, q.symbols, q.start, q.length, 2)
+    assert rc == 0
+    assert np.array_equal(H.matches_as_ref(idx, got),
+                          H.expected("wildcards", "mem2"))
+    m.close()
+
+
+def test_replicate_copies_an_index_device_to_device(V, MG):
+    idx, q = H.load_case("grumbach")
+    i = idx.as_width(32)
+    first = V.Index.from_tables(i.n, i.prefixlength, i.numofchars, i.tis,
+                                i.suf, i.lcp, i.llv, i.bck, i.bwt)
+    single = V.findquerymatches(first, V.Queries.from_host(
+        q.symbols, q.start, q.length), 14, mum=True).fetch()
+    # a clone answers like the original
+    twin = first.clone(0)
+    assert twin.info().device_bytes == first.info().device_bytes
+    assert np.array_equal(V.findquerymatches(twin, V.Queries.from_host(
+        q.symbols, q.start, q.length), 14, mum=True).fetch(), single)
+    twin.close()
+    m = MG.Multi.replicate(first, [0, 0, 0, 0])
+    got, st, rc, msg = m.findmatches(MG.MUM, q.symbols, q.start, q.length, 14)
+    assert rc == 0, msg
+    assert np.array_equal(got, single)
+    assert np.array_equal(H.matches_as_ref(idx, got),
+                          H.expected("grumbach", "mum14"))
+    m.close()
+
+
+def test_errors_and_callbacks_follow_the_reference(V, MG):
+    idx, _, m = tables(MG, "grumbach", [0, 0, 0])
+    q = H.fasta_queries(H.os.path.join(H.GOLDEN, "short.fna"))
+    got, st, rc, msg = m.findmatches(MG.COMPLETE, q.symbols, q.start,
+                                     q.length)
+    # the short query stops the run after the matches before it
+    assert rc < 0 and msg == "patternlength=5 must be >= 6=prefixlen"
+    assert np.array_equal(H.matches_as_ref(idx, got),
+                          H.expected("grumbach", "complete_short"))
+    got, st, rc, msg = m.findmatches(MG.MEM, q.symbols, q.start, q.length, 3)
+    assert rc < 0 and msg == "searchlength=3 must be >= 6=prefixlen"
+    _, q2 = H.load_case("grumbach")
+    want = H.oracle_querymatches(idx, q2, 14, speedup=2)
+    rc, got = m.findmatches_cb(MG.MEM, q2.symbols, q2.start, q2.length, 14)
+    assert rc == 0 and got == [tuple(int(x) for x in r) for r in want.tolist()]
+    rc, got = m.findmatches_cb(MG.MEM, q2.symbols, q2.start, q2.length, 14,
+                               stop_after=7)
+    assert rc != 0 and len(got) == 7
+    # no queries at all
+    e = np.zeros(0, np.uint64)
+    got, st, rc, _ = m.findmatches(MG.MUM, np.zeros(0, np.uint8), e, e, 14)
+    assert rc == 0 and len(got) == 0 and st.count == 0
+    m.close()

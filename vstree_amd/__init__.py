@@ -119,6 +119,7 @@ def _load():
         "vsa_index_download": (I, [V, V, V, V, V, V, V]),
         "vsa_index_set_queryseparator": (I, [V, U64]),
         "vsa_index_set_queryspeedup": (I, [V, U32]),
+        "vsa_index_clone": (I, [V, I, PP]),
         "vsa_mkvtree": (I, [C.POINTER(C.c_char_p), U32, C.POINTER(C.c_char_p),
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
@@ -269,6 +270,12 @@ class Index:
                                       _ptr(out["llv"]), _ptr(out["bck"]),
                                       _ptr(out["bwt"])))
         return out
+
+    def clone(self, device=0):
+        """replica on another device: device-to-device copies, no rebuild"""
+        h = C.c_void_p()
+        _check(lib.vsa_index_clone(self._h, int(device), C.byref(h)))
+        return Index(h)
 
     def set_queryseparator(self, pos):
         _check(lib.vsa_index_set_queryseparator(self._h, int(pos)))

@@ -210,6 +210,113 @@ int vsa_index_alloc(uint64_t n, uint32_t pl, uint32_t numofchars,
   return 0;
 }
 
+// A replica of an index in the memory of another device (or of the same one):
+// every table, the derived search tables included, is copied device to device
+// -- over xGMI between two GPUs of a node -- and nothing is built again.
+extern "C" int vsa_index_clone(const vsa_index *src, int device,
+                               vsa_index **clone)
+{
+  if (src == nullptr || clone == nullptr)
+  {
+    VSA_ERROR("vsa_index_clone: NULL argument");
+    return -1;
+  }
+  *clone = nullptr;
+  vsa_index *ix = nullptr;
+  // same shapes (isize of the source, whatever VSA_FORCE_WIDE says now)
+  int rc = vsa_index_alloc(src->n, src->pl, src->numofchars, src->nllv,
+                           src->bwt != nullptr, device, &ix, false);
+  auto fail = [&](int code) {
+    vsa_index_close(ix);
+    return code;
+  };
+  if (rc != 0)
+  {
+    return fail(rc);
+  }
+  if (ix->isize != src->isize)
+  {
+    // vsa_index_alloc chose 4-byte entries, the source holds 8-byte ones
+    (void) hipFree(ix->suf);
+    (void) hipFree(ix->llv);
+    (void) hipFree(ix->bck);
+    ix->suf = ix->llv = ix->bck = nullptr;
+    ix->isize = src->isize;
+    if (vsa_hip_malloc(&ix->suf, (src->n + 1) * ix->isize) != hipSuccess ||
+        vsa_hip_malloc(&ix->llv, 2 * src->nllv * ix->isize + 16) != hipSuccess ||
+        vsa_hip_malloc(&ix->bck, 2 * ix->numofcodes * ix->isize) != hipSuccess)
+    {
+      VSA_ERROR("vsa_index_clone: out of device memory");
+      return fail(-100);
+    }
+  }
+  const uint64_t n = src->n;
+  struct Piece
+  {
+    void **dst;
+    const void *from;
+    uint64_t bytes;
+    bool allocate;
+  };
+  const uint64_t ncodes = src->D > 0 ? 1ull << (2 * src->D) : 0,
+                 nblocks = (n >> 6) + 1, nwaves = (nblocks + 63) / 64;
+  Piece pieces[] = {
+      {(void **) &ix->tis_alloc, src->tis_alloc,
+       VSA_TIS_FRONTPAD + n + VSA_TIS_BACKPAD, false},
+      {&ix->suf, src->suf, (n + 1) * src->isize, false},
+      {(void **) &ix->lcp, src->lcp, n + 1 + 32, false},
+      {&ix->llv, src->llv, 2 * src->nllv * src->isize, false},
+      {&ix->bck, src->bck, 2 * src->numofcodes * src->isize, false},
+      {(void **) &ix->bwt, src->bwt, n + 1 + 32, false},
+      {(void **) &ix->esa8, src->esa8, (n + 1) * 8 + 64, true},
+      {(void **) &ix->bck2, src->bck2, 2 * ncodes * 4 + 16, true},
+      {(void **) &ix->slot16, src->slot16,
+       (uint64_t) src->slotwords * ncodes * 8 + 32, true},
+      {(void **) &ix->tis2, src->tis2, nblocks * 16 + 64, true},
+      {(void **) &ix->spec64, src->spec64, nwaves * 8 + 64, true}};
+  for (const Piece &p : pieces)
+  {
+    if (p.from == nullptr || p.bytes == 0)
+    {
+      continue;
+    }
+    if (p.allocate)
+    {
+      if (vsa_hip_malloc(p.dst, p.bytes) != hipSuccess)
+      {
+        VSA_ERROR("vsa_index_clone: out of device memory");
+        return fail(-100);
+      }
+      ix->device_bytes += p.bytes;
+    }
+    const hipError_t e =
+        hipMemcpyPeerAsync(*p.dst, device, p.from, src->device, p.bytes,
+                           ix->stream);
+    if (e != hipSuccess)
+    {
+      VSA_ERROR("vsa_index_clone: copy from device %d to device %d: %s",
+                src->device, device, hipGetErrorString(e));
+      return fail(-100);
+    }
+  }
+  if (hipStreamSynchronize(ix->stream) != hipSuccess)
+  {
+    VSA_ERROR("vsa_index_clone: copy failed");
+    return fail(-100);
+  }
+  ix->device_bytes = src->device_bytes;
+  ix->D = src->D;
+  ix->tune = src->tune;
+  ix->qspeedup = src->qspeedup;
+  ix->slotwords = src->slotwords;
+  ix->firstspecial = src->firstspecial;
+  ix->querysepposition = src->querysepposition;
+  ix->hasindexedqueries = src->hasindexedqueries;
+  ix->lcpquirk = src->lcpquirk;
+  *clone = ix;
+  return 0;
+}
+
 extern "C" void vsa_index_close(vsa_index *ix)
 {
   if (ix == nullptr)
