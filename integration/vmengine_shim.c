@@ -42,6 +42,7 @@
 #include "vplugin-interface.h"
 #include "cpridx-data.h"
 #include "vstree_amd.h"
+#include "vstree_amd_multi.h"
 
 /* reference functions this binding keeps using */
 Sint initMatchstate(Matchstate *, Virtualtree *, void *, Matchparam *,
@@ -135,16 +136,14 @@ static int getgpuindex(Virtualtree *virtualtree, int needbwt,
 }
 
 /* the query Multiseq as (start, length) pairs, kurtz-basic/multiseq.c:129 */
-static int getgpuqueries(Multiseq *multiseq, BOOL rcmode,
-                         vsa_queries **queries)
+static int getquerybounds(Multiseq *multiseq, uint64_t **start,
+                          uint64_t **length)
 {
   Uint i, nq = multiseq->numofsequences;
-  uint64_t *start, *length;
-  int rc;
 
-  start = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (nq + 1));
-  length = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (nq + 1));
-  if (start == NULL || length == NULL)
+  *start = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (nq + 1));
+  *length = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (nq + 1));
+  if (*start == NULL || *length == NULL)
   {
     ERROR0("out of memory");
     return -1;
@@ -154,16 +153,131 @@ static int getgpuqueries(Multiseq *multiseq, BOOL rcmode,
     Uint s = (i == 0) ? 0 : multiseq->markpos.spaceUint[i - 1] + 1;
     Uint e = (i == nq - 1) ? multiseq->totallength
                            : multiseq->markpos.spaceUint[i];
-    start[i] = s;
-    length[i] = e - s;
+    (*start)[i] = s;
+    (*length)[i] = e - s;
+  }
+  return 0;
+}
+
+static int getgpuqueries(Multiseq *multiseq, BOOL rcmode,
+                         vsa_queries **queries)
+{
+  uint64_t *start, *length;
+  int rc;
+
+  if (getquerybounds(multiseq, &start, &length) != 0)
+  {
+    return -1;
   }
   rc = vsa_queries_from_host(rcmode ? multiseq->rcsequence
                                     : multiseq->sequence,
-                             multiseq->totallength, start, length, nq, 0,
-                             queries);
+                             multiseq->totallength, start, length,
+                             multiseq->numofsequences, 0, queries);
   free(start);
   free(length);
   return rc != 0 ? gpufail() : 0;
+}
+
+/* ---- all GPUs of the node (include/vstree_amd_multi.h) -------------------
+   VMATCH_GPUS=N        replicas on devices 0 .. N-1
+   VMATCH_GPU_DEVICES=a,b,c   replicas on exactly these devices (a device may
+                        be named twice: how a one-GPU box rehearses it)
+   Exact -complete, -l, -mum cand and -mum then run on all replicas: the
+   queries are cut into blocks, the match lists come back in the reference's
+   order and go through the same sinks as in the single-GPU case. */
+#define MAXGPUS 64
+static vsa_multi *gpumulti = NULL;
+static Virtualtree *gpumultiowner = NULL;
+
+static uint32_t multidevices(int *devices)
+{
+  const char *list = getenv("VMATCH_GPU_DEVICES"), *n = getenv("VMATCH_GPUS");
+  uint32_t count = 0;
+
+  if (list != NULL && *list != '\0')
+  {
+    while (*list != '\0' && count < MAXGPUS)
+    {
+      devices[count++] = (int) strtol(list, (char **) &list, 10);
+      while (*list == ',' || *list == ' ')
+      {
+        list++;
+      }
+    }
+  } else if (n != NULL && atoi(n) > 1)
+  {
+    for (count = 0; count < (uint32_t) atoi(n) && count < MAXGPUS; count++)
+    {
+      devices[count] = (int) count;
+    }
+  }
+  return count > 1 ? count : 0;
+}
+
+static int getgpumulti(Virtualtree *virtualtree, const int *devices,
+                       uint32_t ndevices, vsa_multi **multi)
+{
+  vsa_tables t;
+
+  if (gpumulti != NULL && gpumultiowner == virtualtree)
+  {
+    *multi = gpumulti;
+    return 0;
+  }
+  if (gpumulti != NULL)
+  {
+    vsa_multi_close(gpumulti);
+    gpumulti = NULL;
+  }
+  memset(&t, 0, sizeof t);
+  t.totallength = virtualtree->multiseq.totallength;
+  t.prefixlength = (uint32_t) virtualtree->prefixlength;
+  t.numofchars = (uint32_t) (virtualtree->alpha.mapsize - 1);
+  t.integersize = (uint32_t) (8 * sizeof(Uint));
+  t.largelcpvalues = virtualtree->largelcpvalues.nextfreePairUint;
+  t.tis = virtualtree->multiseq.sequence;
+  t.suf = virtualtree->suftab;
+  t.lcp = virtualtree->lcptab;
+  t.llv = virtualtree->largelcpvalues.spacePairUint;
+  t.bck = virtualtree->bcktab;
+  if (vsa_multi_from_tables(&t, devices, ndevices, &gpumulti) != 0)
+  {
+    return gpufail();
+  }
+  gpumultiowner = virtualtree;
+  *multi = gpumulti;
+  return 0;
+}
+
+/* one exact engine call on all replicas; the matches go to `sink` */
+static int runonallgpus(Virtualtree *virtualtree, Multiseq *queries,
+                        BOOL rcmode, int mode, Uint searchlength,
+                        Uint queryspeedup, const int *devices,
+                        uint32_t ndevices, vsa_processmatch sink, void *info)
+{
+  vsa_multi *multi;
+  uint64_t *start, *length;
+  uint32_t r;
+  int rc;
+
+  if (getgpumulti(virtualtree, devices, ndevices, &multi) != 0 ||
+      getquerybounds(queries, &start, &length) != 0)
+  {
+    return -2;
+  }
+  for (r = 0; r < vsa_multi_ndevices(multi); r++)
+  {
+    (void) vsa_index_set_queryspeedup(vsa_multi_index(multi, r),
+                                      (uint32_t) queryspeedup);
+  }
+  rc = vsa_multi_findmatches_cb(multi, mode, searchlength,
+                                rcmode ? queries->rcsequence
+                                       : queries->sequence,
+                                queries->totallength, start, length,
+                                queries->numofsequences, sink, info);
+  free(start);
+  free(length);
+  return rc;
 }
 
 /* ---- vmatch -complete -q ------------------------------------------------ */
@@ -258,6 +372,26 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
     return (Sint) -1;
   }
   cpridxpatsearchdata->voidMatchstate = NULL;
+  {
+    int devices[MAXGPUS];
+    const uint32_t ndevices = multidevices(devices);
+    if (ndevices > 0 && !approx)
+    {
+      rc = runonallgpus(virtualtree, queryinfo->multiseq, rcmode,
+                        VSA_MULTI_COMPLETE, 0, 2, devices, ndevices,
+                        completesink, &matchstate);
+      trace("complete matches, all replicas");
+      if (rc != 0)
+      {
+        if (rc != -1)
+        {
+          (void) gpufail();
+        }
+        return (Sint) -2;
+      }
+      return 0;
+    }
+  }
   if (getgpuindex(virtualtree, 0, &index) != 0 ||
       getgpuqueries(queryinfo->multiseq, rcmode, &queries) != 0)
   {
@@ -351,6 +485,31 @@ Sint __wrap_findquerymatches(Virtualtree *virtualtree,
                      domatchbuffering) != 0)
   {
     return (Sint) -1;
+  }
+  {
+    int devices[MAXGPUS];
+    const uint32_t ndevices = multidevices(devices);
+    if (ndevices > 0)
+    {
+      rc = runonallgpus(virtualtree, queryinfo->multiseq, rcmode,
+                        !domaximaluniquematch
+                            ? VSA_MULTI_MEM
+                            : (domaximaluniquematchcandidates
+                                   ? VSA_MULTI_MUMCAND
+                                   : VSA_MULTI_MUM),
+                        matchparam->seedlength, matchparam->queryspeedup,
+                        devices, ndevices, querysink, &matchstate);
+      trace("query matches, all replicas");
+      if (rc != 0)
+      {
+        if (rc != -1)
+        {
+          (void) gpufail();
+        }
+        return (Sint) -1;
+      }
+      return 0;
+    }
   }
   if (getgpuindex(virtualtree, 0, &index) != 0 ||
       getgpuqueries(queryinfo->multiseq, rcmode, &queries) != 0)

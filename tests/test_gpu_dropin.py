@@ -94,6 +94,32 @@ def test_vmatch_with_gpu_engine_prints_reference_output(case, tmp_path):
 
 
 @needs_binaries
+@pytest.mark.parametrize("case", ["c1", "grumbach", "micro"])
+def test_vmatch_on_several_replicas_prints_reference_output(case, tmp_path):
+    """VMATCH_GPU_DEVICES=0,0,0: the shim's multi-GPU path (vsa_multi_*, one
+    host thread per replica) with three replicas on the one GPU of the box --
+    same stdout as the reference, engine calls traced as 'all replicas'."""
+    wd = str(tmp_path)
+    stage(case, wd)
+    H.run_mkvtree_ref(MKV[case] + ["-dna", "-pl", "-allout"], wd)
+    seen = 0
+    for key, run in sorted(M[case]["runs"].items()):
+        if not key.startswith(("complete", "mem", "mum")):
+            continue
+        rc, lines, err = run_gpu_vmatch(
+            run["args"], wd, {"VMATCH_GPU_TRACE": "1",
+                              "VMATCH_GPU_DEVICES": "0,0,0"})
+        assert (rc != 0) == (run["rc"] != 0), (key, err)
+        assert "all replicas on the GPU" in err, (case, key, err)
+        if run["rc"] != 0:
+            assert run["stderr"].split(": ", 1)[1] in err
+        md5 = hashlib.md5(("\n".join(lines) + "\n").encode()).hexdigest()
+        assert md5 == run["md5_lines"], (case, key)
+        seen += 1
+    assert seen >= 4
+
+
+@needs_binaries
 def test_gpu_switch_off_gives_the_reference_engine(tmp_path):
     wd = str(tmp_path)
     stage("micro", wd)

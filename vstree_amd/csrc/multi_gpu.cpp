@@ -673,7 +673,7 @@ extern "C" int vsa_multi_findmatches_cb(vsa_multi *m, int mode,
   {
     if (processmatch(info, matches + i) != 0)
     {
-      rc = 1; // stopped by the callback (Processfinalfunction != 0)
+      rc = -1; // stopped by the callback, like the single-GPU entries
       break;
     }
   }
