@@ -226,6 +226,40 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
         log("reference vmatch: index files %.0f s, 1 core %.1f s (%d queries),"
             " %d cores %.1f s (%d queries)" % (t_index, t1, ns1, ncores, tp,
                                                nsp))
+        # the drop-in binary (reference vmatch + integration/vmengine_shim.c)
+        # on the same files: whole process, incl. mapping the index, its
+        # upload to HBM, the derived tables, FASTA parsing and printing
+        dropin = None
+        gpubin = os.path.join(ROOT, "integration", "_build", "vmatch_gpu")
+        if os.access(gpubin, os.X_OK):
+            with open(wd + "/qall.fna", "wb") as f:
+                for p in range(ncores):
+                    with open(wd + "/qp%d.fna" % p, "rb") as g:
+                        shutil.copyfileobj(g, f)
+            genv = dict(os.environ, VMATCH_GPU_TRACE="1")
+            td = time.time()
+            pr = subprocess.run([gpubin, "-mum", "-l", str(L), "-q",
+                                 "qall.fna", "genome.fna"], cwd=wd, env=genv,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            td = time.time() - td
+            nm = sum(1 for l in pr.stdout.splitlines()
+                     if l and not l.startswith(b"#"))
+            trace = [l for l in pr.stderr.decode().splitlines()
+                     if l.startswith("vstree_amd:")]
+            log("drop-in vmatch_gpu: %.1f s for %d queries, %d MUMs; %s"
+                % (td, nsp, nm, "; ".join(trace)))
+            # (its MUM count differs from the sum over the 16 slices above:
+            # uniqueness is judged over ALL queries of a run; the drop-in's
+            # output is compared with the reference's in tests/)
+            if pr.returncode == 0 and nm > 0:
+                dropin = {"value": nsp / td, "unit": "queries/s",
+                          "wall_s": td, "queries": nsp, "mums": nm,
+                          "what": "integration/_build/vmatch_gpu -mum -l %d "
+                                  "-q (the reference program with the GPU "
+                                  "engine linked in): whole process, index "
+                                  "files -> HBM included" % L,
+                          "trace": trace,
+                          "reference_same_queries_16_processes_s": tp}
         return {
             "value": nsp / tp, "unit": "queries/s", "cores": ncores,
             "kind": "reference",
@@ -243,7 +277,7 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
                 "kind": "reference",
                 "sample": "%d queries, one process, %.1f s, %d MUMs"
                           % (ns1, t1, c1[0])},
-            "mums_1core_sample": c1[0]}
+            "mums_1core_sample": c1[0], "dropin_end_to_end": dropin}
     finally:
         shutil.rmtree(wd, ignore_errors=True)
 
@@ -389,10 +423,11 @@ def main():
             res.close()
             return st.count, st.sumlength
 
+        # (the counters stay local: ONE all-reduce at the end of the job)
         nmum, sumlen, ncand, searches, ksearches = \
             S.partitioned_mum_filter_presorted(
                 dist, torch, mine, send, top, cdev, filter_fn, words=2,
-                extra=[s.searches, s.kernel_searches])
+                extra=[s.searches, s.kernel_searches], reduce=False)
         totals = (nmum, sumlen, searches, ncand, ksearches)
 
     for _ in range(a.warmup):
@@ -403,6 +438,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
+    if distributed:
+        # the final match-count reduction of the job (every step produces the
+        # same counters here; a real job would have summed them over its
+        # batches first)
+        totals = tuple(S.all_reduce_counters(
+            dist, torch, totals, "cpu" if a.rehearse_on_one_gpu else "cuda"))
     sync()
     elapsed = time.perf_counter() - t0
     if distributed:

@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "types.h"
 #include "errordef.h"
 #include "virtualdef.h"
@@ -88,6 +89,23 @@ static void trace(const char *what)
   }
 }
 
+static double nowseconds(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+static void tracetime(const char *what, double since)
+{
+  const char *e = getenv("VMATCH_GPU_TRACE");
+  if (e != NULL && strcmp(e, "0") != 0)
+  {
+    fprintf(stderr, "vstree_amd: %s took %.3f s\n", what,
+            nowseconds() - since);
+  }
+}
+
 static int gpufail(void)
 {
   ERROR1("%s", vsa_messagespace());
@@ -126,9 +144,13 @@ static int getgpuindex(Virtualtree *virtualtree, int needbwt,
     t.hasindexedqueries = 1;
     t.querysepposition = getqueryseppos(&virtualtree->multiseq);
   }
-  if (vsa_index_from_tables(&t, 0, &gpuindex) != 0)
   {
-    return gpufail();
+    const double t0 = nowseconds();
+    if (vsa_index_from_tables(&t, 0, &gpuindex) != 0)
+    {
+      return gpufail();
+    }
+    tracetime("index upload (tables to HBM + derived search tables)", t0);
   }
   gpuindexowner = virtualtree;
   *index = gpuindex;
@@ -518,10 +540,15 @@ Sint __wrap_findquerymatches(Virtualtree *virtualtree,
   }
   (void) vsa_index_set_queryspeedup(index,
                                     (uint32_t) matchparam->queryspeedup);
-  rc = vsa_findquerymatches_cb(index, queries, domaximaluniquematch ? 1 : 0,
-                               domaximaluniquematchcandidates ? 1 : 0,
-                               matchparam->seedlength, querysink,
-                               &matchstate);
+  {
+    const double t0 = nowseconds();
+    rc = vsa_findquerymatches_cb(index, queries,
+                                 domaximaluniquematch ? 1 : 0,
+                                 domaximaluniquematchcandidates ? 1 : 0,
+                                 matchparam->seedlength, querysink,
+                                 &matchstate);
+    tracetime("engine call + delivery of the matches to processfinal", t0);
+  }
   trace("query matches");
   vsa_queries_free(queries);
   if (rc != 0)

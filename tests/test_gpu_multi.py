@@ -127,3 +127,39 @@ def test_errors_and_callbacks_follow_the_reference(V, MG):
     got, st, rc, _ = m.findmatches(MG.MUM, np.zeros(0, np.uint8), e, e, 14)
     assert rc == 0 and len(got) == 0 and st.count == 0
     m.close()
+
+
+def test_two_processes_on_one_gpu_run_the_exchange_for_real(tmp_path):
+    """bench.py's N > 1 path with TWO processes on the one GPU of the box:
+    vsa_findmumcandidates_packed -> vsa_result_partition -> exchange (gloo on
+    host copies, the box has no second GPU for RCCL) ->
+    vsa_mumuniqueinquery_range_packed with carries; the job-wide counters must
+    be those of one process answering all queries."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = ["--genome", "3e7", "--steps", "2", "--warmup", "1", "--quick",
+              "--cpu-sample", "0"]
+    bench = H.os.path.join(H.ROOT, "bench.py")
+    two = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), bench, "--gpus", "2",
+         "--rehearse-on-one-gpu", "--queries", "150000"] + common,
+        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert two.returncode == 0, two.stderr.decode()[-2000:]
+    one = subprocess.run([sys.executable, bench, "--queries", "300000"] +
+                         common, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    a = json.loads(two.stdout.decode().strip().splitlines()[-1])
+    b = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    assert a["n_gpus"] == 2 and b["n_gpus"] == 1
+    assert a["matches"] == b["matches"] > 250000
+    assert a["candidates"] == b["candidates"] >= a["matches"]
+    assert a["query_suffix_searches"] == b["query_suffix_searches"]

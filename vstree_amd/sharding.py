@@ -104,7 +104,7 @@ def _exchange_rows(dist, torch, rows, dest, device):
 
 def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
                                      device, filter_fn, words=MATCH_WORDS,
-                                     extra=()):
+                                     extra=(), reduce=True):
     """partitioned_mum_filter for candidates that vsa_result_partition has
     grouped by destination already (send[r] rows for rank r, maxright[r] =
     their largest right end): no sorting on this side and three collectives --
@@ -113,7 +113,10 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     the counters.  words = 8-byte words per row: 4 for records, 2 for the
     (key, value) pairs of vsa_findmumcandidates_packed.  extra: more local
     counters to sum over the ranks in the same all-reduce; their totals
-    follow the three results."""
+    follow the three results.  reduce=False: no all-reduce -- the counters
+    returned are this rank's own, for a caller that sums them over many
+    batches and reduces once at the end of the job (the only collective the
+    counters need)."""
     world, me = dist.get_world_size(), dist.get_rank()
     rows = rows.reshape(-1, words)
     meta = torch.as_tensor(np.concatenate([np.asarray(send, np.int64),
@@ -141,8 +144,9 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
             keep.append(p.reshape(-1, words)[off:off + recv[r]])
         mine = torch.cat(keep) if keep else rows[:0]
     nmum, sumlen = filter_fn(mine.reshape(-1), carry)
-    totals = all_reduce_counters(
-        dist, torch, [nmum, sumlen, rows.shape[0]] + list(extra), device)
+    local = [nmum, sumlen, rows.shape[0]] + list(extra)
+    totals = (all_reduce_counters(dist, torch, local, device) if reduce
+              else [int(v) for v in local])
     return tuple(totals) if extra else tuple(totals[:3])
 
 
