@@ -559,6 +559,8 @@ def main():
         if extras:
             fams += extra_families(a, V, H, index, queries, q150, host, small,
                                    w, nq, m, L, bytes_per_query, cbytes)
+            out["end_to_end"] = end_to_end(V, index, g, pos, sub, step, nq, m,
+                                           L)
         out["roofline_families"] = fams
         if world == 1 and a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baselines(
@@ -623,6 +625,56 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
         "%d start positions x (154 text + 150 pattern symbols)"
         % s.kernel_searches, traffic_key="k_apm_banded", queries=nq))
     return fams
+
+
+def end_to_end(V, index, g, pos, sub, step, nq, m, L, batches=8):
+    """queries in (page-locked) host memory -> MUMs in host memory through
+    vsa_pipeline_*: three batches in flight, upload / search / download
+    overlapped; the global MUM filter over all batches and the download of
+    its list are part of the timed region"""
+    p = V.Pipeline(index, 3, L, m, nq)
+    first = None
+    for _ in range(3):                 # the three slots hold the batch
+        buf = p.hostbuffer()
+        rows = buf[:nq * m].reshape(nq, m)
+        if first is None:
+            chunk = 1 << 20            # the reads of the plan, from the text
+            for a0 in range(0, nq, chunk):
+                a1 = min(nq, a0 + chunk)
+                rows[a0:a1] = g[pos[a0:a1, None].astype(np.int64) +
+                                np.arange(m)[None, :]]
+            hit = np.flatnonzero(sub != V.NO_SUBST)
+            rows[hit, sub[hit]] = (rows[hit, sub[hit]] + step[hit]) & 3
+            first = rows
+        else:
+            rows[:] = first
+        p.submit(nq)
+    for _ in range(3):
+        p.next(copy=False)
+    p.finish()                         # warm-up job done
+    t0 = time.perf_counter()
+    sub = got = 0
+    while got < batches:
+        buf = p.hostbuffer() if sub < batches else None
+        if buf is not None:
+            p.submit(nq)               # the slot still holds the reads
+            sub += 1
+        else:
+            p.next(copy=False)
+            got += 1
+    mums, st = p.finish()
+    dt = time.perf_counter() - t0
+    p.close()
+    return {"end_to_end_queries_per_s": batches * nq / dt,
+            "batches": batches, "queries_per_batch": nq,
+            "ms_per_batch": dt / batches * 1e3, "mums": int(len(mums)),
+            "candidates": int(st.candidates),
+            "what": "vsa_pipeline_*: %d batches of %d reads from page-locked "
+                    "host memory (%.2f GB each over PCIe) to the MUM list of "
+                    "the whole job in host memory (%.2f GB): uploads, "
+                    "searches and the final filter + download, three batches "
+                    "in flight" % (batches, nq, nq * m / 1e9,
+                                   len(mums) * 32 / 1e9)}
 
 
 def selfmum_family(a, V, n, L, dev):

@@ -473,6 +473,40 @@ int vsa_findmaximalrepeats_cb(const vsa_index *index, uint64_t searchlength,
 int vsa_findtandems_cb(const vsa_index *index, uint64_t searchlength,
                        vsa_processmatch processmatch, void *info);
 
+/* ---- end to end: queries in host memory -> matches in host memory ------
+   Three batches in flight: while one is searched, the next is uploaded and
+   the matches of the one before are downloaded (page-locked buffers the caller
+   fills and reads in place, one HIP stream per direction).  Reads of one
+   length, packed back to back.  mode: 0 -complete, 1 -l L (MEM), 2 -mum cand,
+   3 -mum (candidates of all batches stay on the device; the filter of
+   kurtz/cleanMUMcand.c:55-118 runs once, in vsa_pipeline_finish).  queryseq
+   of a match counts over all batches (Vmengine/fquery.c:1010
+   onlinequerynumoffset).
+
+     vsa_pipeline_open(index, 3, 20, 100, 10000000, &p);
+     while (more reads) {
+       uint8_t *buf;
+       while ((buf = vsa_pipeline_hostbuffer(p)) == NULL)
+         vsa_pipeline_next(p, &m, &n);          -- take a finished batch
+       n_reads = fill(buf);  vsa_pipeline_submit(p, n_reads);
+     }
+     while (vsa_pipeline_next(p, &m, &n) != 1) ...;
+     vsa_pipeline_finish(p, &mums, &nmums, &stats);                        */
+typedef struct vsa_pipeline vsa_pipeline;
+int vsa_pipeline_open(const vsa_index *index, int mode, uint64_t searchlength,
+                      uint32_t querylength, uint64_t maxqueries,
+                      vsa_pipeline **pipeline);
+uint8_t *vsa_pipeline_hostbuffer(vsa_pipeline *pipeline);
+int vsa_pipeline_submit(vsa_pipeline *pipeline, uint64_t numofqueries);
+/* 0: the oldest batch not yet delivered (host memory, valid until the next
+   call that needs its slot); 1: nothing outstanding; < 0: that batch failed
+   (message in vsa_messagespace(), matches up to the error delivered) */
+int vsa_pipeline_next(vsa_pipeline *pipeline, const vsa_match **matches,
+                      uint64_t *count);
+int vsa_pipeline_finish(vsa_pipeline *pipeline, const vsa_match **matches,
+                        uint64_t *count, vsa_stats *stats);
+void vsa_pipeline_close(vsa_pipeline *pipeline);
+
 /* ---- synthetic inputs (bench.py, tests): SURVEY.md section 8d ---------- */
 
 uint64_t vsa_splitmix64_at(uint64_t seed, uint64_t idx);

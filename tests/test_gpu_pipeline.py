@@ -1,0 +1,88 @@
+"""vsa_pipeline_*: queries from host memory to matches in host memory, three
+batches in flight.  The batches of a job, concatenated, must be the reference's
+list (query numbers count over the whole job; -mum filters over all batches)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_parity import gpu_index
+
+pytestmark = pytest.mark.gpu
+
+
+def run_job(V, gi, q, mode, L, per):
+    m = int(q.length[0])
+    p = V.Pipeline(gi, mode, L, m, per)
+    sym = q.symbols.reshape(q.nq, m)
+    out, first = [], 0
+    while first < q.nq:
+        buf = p.hostbuffer()
+        while buf is None:                 # all slots in flight: take one
+            rc, got = p.next()
+            assert rc == 0
+            out.append(got)
+            buf = p.hostbuffer()
+        n = min(per, q.nq - first)
+        buf[:n * m] = sym[first:first + n].ravel()
+        p.submit(n)
+        first += n
+    while True:
+        rc, got = p.next()
+        if rc == 1:
+            break
+        assert rc == 0
+        out.append(got)
+    res = np.concatenate(out) if out else np.zeros(0, V.MATCH_DTYPE)
+    if mode == 3:
+        assert len(res) == 0
+        res, st = p.finish()
+        assert st.count == len(res)
+    p.close()
+    return res
+
+
+@pytest.mark.parametrize("per", [10000, 3000, 999, 64])
+def test_batches_of_a_job_concatenate_to_the_reference_list(V, per):
+    idx, q = H.load_case("c1")
+    gi = gpu_index(V, "c1")
+    gi.set_queryspeedup(2)
+    for mode, key, L in ((0, "complete", 0), (2, "mumcand20", 20),
+                         (3, "mum20", 20), (1, "mem20_sp2", 20)):
+        got = run_job(V, gi, q, mode, L, per)
+        assert np.array_equal(H.matches_as_ref(idx, got),
+                              H.expected("c1", key)), (per, key)
+
+
+def test_slots_are_reused_and_errors_surface_per_batch(V):
+    idx, q = H.load_case("c1")
+    gi = gpu_index(V, "c1")
+    m = 100
+    p = V.Pipeline(gi, 0, 0, m, 500)
+    sym = q.symbols.reshape(q.nq, m)
+    # three submissions fill the pipeline; the fourth buffer needs a slot
+    for b in range(3):
+        buf = p.hostbuffer()
+        assert buf is not None
+        buf[:500 * m] = sym[b * 500:(b + 1) * 500].ravel()
+        p.submit(500)
+    assert p.hostbuffer() is None
+    want = H.oracle_complete(idx, H.Queries.uniform(sym[:1500].ravel(), m))
+    got = []
+    for b in range(3):
+        rc, a = p.next()
+        assert rc == 0
+        got.append(a)
+    assert np.array_equal(np.concatenate(got), want)
+    assert p.next()[0] == 1
+    # a pipeline whose reads are shorter than prefixlength: the reference's
+    # hard error, reported for the batch
+    p.close()
+    p = V.Pipeline(gi, 0, 0, 5, 10)
+    buf = p.hostbuffer()
+    buf[:50] = 0
+    p.submit(10)
+    rc, a = p.next()
+    assert rc < 0 and "must be >= " in V.messagespace()
+    p.close()
+    with pytest.raises(V.VsaError):
+        V.Pipeline(gi, 7, 20, 100, 10)

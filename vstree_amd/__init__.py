@@ -120,6 +120,13 @@ def _load():
         "vsa_index_set_queryseparator": (I, [V, U64]),
         "vsa_index_set_queryspeedup": (I, [V, U32]),
         "vsa_index_clone": (I, [V, I, PP]),
+        "vsa_pipeline_open": (I, [V, I, U64, U32, U64, PP]),
+        "vsa_pipeline_hostbuffer": (V, [V]),
+        "vsa_pipeline_submit": (I, [V, U64]),
+        "vsa_pipeline_next": (I, [V, PP, C.POINTER(U64)]),
+        "vsa_pipeline_finish": (I, [V, PP, C.POINTER(U64),
+                                    C.POINTER(Stats)]),
+        "vsa_pipeline_close": (None, [V]),
         "vsa_mkvtree": (I, [C.POINTER(C.c_char_p), U32, C.POINTER(C.c_char_p),
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
@@ -568,6 +575,62 @@ def findmaximaluniquematches_cb(index, searchlength, stop_after=None):
     rc = lib.vsa_findmaximaluniquematches_cb(index._h, int(searchlength), cb,
                                              None)
     return rc, got
+
+
+class Pipeline:
+    """vsa_pipeline_*: host memory in, host memory out, three batches in
+    flight.  mode: 0 -complete, 1 MEM, 2 -mum cand, 3 -mum."""
+
+    def __init__(self, index, mode, searchlength, querylength, maxqueries):
+        self._h = None
+        h = C.c_void_p()
+        _check(lib.vsa_pipeline_open(index._h, int(mode), int(searchlength),
+                                     int(querylength), int(maxqueries),
+                                     C.byref(h)))
+        self._h, self._index = h, index
+        self.m, self.maxqueries = int(querylength), int(maxqueries)
+
+    def hostbuffer(self):
+        """numpy view of the page-locked buffer of the next batch, or None
+        when all batches are in flight"""
+        p = lib.vsa_pipeline_hostbuffer(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(
+            (C.c_uint8 * (self.m * self.maxqueries)).from_address(p))
+
+    def submit(self, nq):
+        _check(lib.vsa_pipeline_submit(self._h, int(nq)))
+
+    def next(self, copy=True):
+        """-> (rc, matches): rc 1 = nothing outstanding"""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        rc = lib.vsa_pipeline_next(self._h, C.byref(ptr), C.byref(n))
+        if rc == 1 or n.value == 0:
+            return rc, np.zeros(0, MATCH_DTYPE)
+        a = np.ctypeslib.as_array(
+            (C.c_uint64 * (4 * n.value)).from_address(ptr.value)).view(
+                MATCH_DTYPE)
+        return rc, a.copy() if copy else a
+
+    def finish(self):
+        ptr, n, st = C.c_void_p(), C.c_uint64(), Stats()
+        _check(lib.vsa_pipeline_finish(self._h, C.byref(ptr), C.byref(n),
+                                       C.byref(st)))
+        if n.value == 0:
+            return np.zeros(0, MATCH_DTYPE), st
+        a = np.ctypeslib.as_array(
+            (C.c_uint64 * (4 * n.value)).from_address(ptr.value)).view(
+                MATCH_DTYPE)
+        return a.copy(), st
+
+    def close(self):
+        if self._h and lib is not None:
+            lib.vsa_pipeline_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 # ---- host match sink ------------------------------------------------------
