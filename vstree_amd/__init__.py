@@ -613,7 +613,7 @@ class Pipeline:
                 MATCH_DTYPE)
         return rc, a.copy() if copy else a
 
-    def finish(self):
+    def finish(self, copy=True):
         ptr, n, st = C.c_void_p(), C.c_uint64(), Stats()
         _check(lib.vsa_pipeline_finish(self._h, C.byref(ptr), C.byref(n),
                                        C.byref(st)))
@@ -622,7 +622,7 @@ class Pipeline:
         a = np.ctypeslib.as_array(
             (C.c_uint64 * (4 * n.value)).from_address(ptr.value)).view(
                 MATCH_DTYPE)
-        return a.copy(), st
+        return (a.copy() if copy else a), st
 
     def close(self):
         if self._h and lib is not None:

@@ -83,7 +83,8 @@ struct vsa_pipeline
   // -mum: candidate rows (key, value) of all batches, one device buffer
   uint64_t *rows = nullptr;
   uint64_t nrows = 0, rowcap = 0, candidates = 0;
-  vsa_match *hostmums = nullptr;
+  vsa_match *hostmums = nullptr; // page-locked, kept between jobs
+  uint64_t hostmumscap = 0;
   int failed = 0;
   std::string failure;
 };
@@ -492,18 +493,30 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
     return rc;
   }
   const uint64_t c = vsa_result_count(res);
-  if (p->hostmums != nullptr)
-  {
-    (void) hipHostFree(p->hostmums);
-    p->hostmums = nullptr;
-  }
   int out = 0;
-  if (c > 0 &&
-      (hipHostMalloc((void **) &p->hostmums, c * sizeof(vsa_match),
-                     hipHostMallocDefault) != hipSuccess ||
-       vsa_result_fetch(res, p->hostmums, c) != 0))
+  if (c > p->hostmumscap)
   {
-    VSA_ERROR("vsa_pipeline_finish: copy of the MUMs to the host failed");
+    // page-locking costs about a third of a second per GB: the buffer is
+    // kept for the next job
+    if (p->hostmums != nullptr)
+    {
+      (void) hipHostFree(p->hostmums);
+      p->hostmums = nullptr;
+    }
+    p->hostmumscap = c + c / 8 + 1024;
+    if (hipHostMalloc((void **) &p->hostmums,
+                      p->hostmumscap * sizeof(vsa_match),
+                      hipHostMallocDefault) != hipSuccess)
+    {
+      (void) hipGetLastError();
+      p->hostmumscap = 0;
+      VSA_ERROR("vsa_pipeline_finish: no page-locked memory for %lu MUMs",
+                (unsigned long) c);
+      out = -100;
+    }
+  }
+  if (out == 0 && c > 0 && vsa_result_fetch(res, p->hostmums, c) != 0)
+  {
     out = -100;
   }
   if (stats != nullptr)
