@@ -27,13 +27,14 @@
   edit distance the reported length is that of the best-distance, then
   longest prefix of the text behind the start position (longestmatch.c).
 
-  This restatement covers the piece threshold 0 with at least two pieces
-  (k < splitsize: the pigeonhole case, every read-length configuration such
-  as m=150,k=2 or m=100,k=2) where the piece search is an exact search; it
-  answers -4 ("not covered") for the others (splitsize 1 or piece threshold
-  > 0: the reference then walks the suffix array with a Myers column per
-  depth, esaapm.c).  Dynamic programming is done cell by cell here (the reference
-  uses cut-off columns or bit vectors, which compute the same values).
+  Pieces with threshold 0 (k < splitsize: the pigeonhole case, every
+  read-length configuration such as m=150,k=2 or m=100,k=2) are searched
+  exactly; pieces with a threshold of their own (k >= m/10) and patterns that
+  are not cut at all (splitsize 1: short patterns) go through esaapm /
+  esahamming (esaapm.c:296-383, esahamming.c:86-164), restated from what they
+  report (hamminghits, edithits).  Dynamic programming is done cell by cell
+  here (the reference uses cut-off columns or bit vectors, which compute the
+  same values).
 
   A match is (length, dbstart, queryseq, distance) with the distance in the
   querystart field (number of mismatches for Hamming; the reference stores
@@ -373,6 +374,189 @@ static void verifyhamming(const orc_index *ix, const uint8_t *p, uint64_t m,
   }
 }
 
+/*
+  esahamming (Vmengine/esahamming.c:86-164), restated from what it reports:
+  it walks the suffixes 0 .. n-1 in suffix array order with a stack of
+  mismatch counts per depth and the skip table; a suffix is reported iff its
+  first plen symbols exist, hold no separator and differ from the pattern in
+  at most `threshold` places (bytes are compared: a wildcard of the pattern
+  equals a wildcard of the text, :66), with that number of mismatches.
+  Suffixes that share more symbols with their predecessor than were looked
+  at (lcp > dvalue+1) are skipped and inherit its verdict -- the same verdict
+  a comparison of their own gives, since the symbols looked at are shared.
+*/
+typedef void (*Hitfunction)(void *info, uint64_t pos, uint64_t value);
+
+static void hamminghits(const orc_index *ix, const uint8_t *p, uint64_t plen,
+                        uint64_t threshold, Hitfunction report, void *info)
+{
+  uint64_t i;
+
+  for (i = 0; i < ix->n; i++)
+  {
+    const uint64_t s = sufat(ix, i);
+    uint64_t d, mm = 0;
+    int ok = ix->n - s >= plen;
+
+    for (d = 0; ok && d < plen; d++)
+    {
+      const uint8_t c = ix->tis[s + d];
+      if (c == ORC_SEPARATOR || (c != p[d] && ++mm > threshold))
+      {
+        ok = 0;
+      }
+    }
+    if (ok)
+    {
+      report(info, s, mm);
+    }
+  }
+}
+
+/*
+  esaapm (Vmengine/esaapm.c:296-383): suffixes in suffix array order; for each
+  the distance column of the pattern against the first d symbols of the
+  suffix is advanced (nextEDcolumn :143-243, Eq masks of getEqs4 in which a
+  wildcard matches nothing) for d = 1 .. maxlength = min(plen + threshold,
+  symbols left in the text) until column d-1 has its last entry <= threshold
+  (success, reported with `maxlength`), a separator is met, or no entry of the
+  column is <= threshold any more.  dvalue = the depth the walk stopped at; a
+  suffix whose lcp byte with its predecessor exceeds dvalue is skipped
+  together with all that follow it while their lcp bytes exceed dvalue (the
+  skip table jumps over them): they inherit the verdict AND are all reported
+  with the maxlength of the FIRST skipped suffix (SETMAXLENGTH runs at the
+  top of the loop, the macro APMSUCCESS reads that variable, :341-378) --
+  restated as it stands.
+*/
+static void edithits(const orc_index *ix, const uint8_t *p, uint64_t plen,
+                     uint64_t threshold, Hitfunction report, void *info)
+{
+  uint64_t i, dvalue = 0, maxlength = 0, col[2 * DPWORDSIZE4 + 2];
+  int success = 0, skipping = 0;
+
+  for (i = 0; i < ix->n; i++)
+  {
+    const uint64_t s = sufat(ix, i);
+    const uint64_t vlen = ix->n - s;
+    const int evaluate = i == 0 || dvalue >= (uint64_t) ix->lcp[i];
+
+    if (evaluate || !skipping)
+    {
+      maxlength = plen + threshold;
+      if (maxlength > vlen)
+      {
+        maxlength = vlen;
+      }
+    }
+    skipping = !evaluate;
+    if (evaluate)
+    {
+      uint64_t d, k;
+
+      for (k = 0; k <= plen; k++)
+      {
+        col[k] = k;
+      }
+      success = 0;
+      dvalue = maxlength;
+      for (d = 1; d <= maxlength; d++)
+      {
+        uint64_t nw, alive = 0;
+        const uint8_t c = ix->tis[s + d - 1];
+
+        if (col[plen] <= threshold)
+        {
+          dvalue = d - 1;
+          break;
+        }
+        if (c == ORC_SEPARATOR)
+        {
+          dvalue = d - 1;
+          break;
+        }
+        nw = col[0];
+        col[0] = d;
+        for (k = 1; k <= plen; k++)
+        {
+          const uint64_t we = col[k];
+          uint64_t val = (p[k - 1] == c && c != ORC_WILDCARD) ? nw : nw + 1;
+          if (col[k - 1] + 1 < val)
+          {
+            val = col[k - 1] + 1;
+          }
+          if (we + 1 < val)
+          {
+            val = we + 1;
+          }
+          col[k] = val;
+          nw = we;
+        }
+        for (k = 0; k <= plen; k++)
+        {
+          alive |= col[k] <= threshold;
+        }
+        if (!alive)
+        {
+          /* column d is dead: the walk stands at d-1, whose last entry is
+             above the threshold (it was tested at the top of the round) */
+          dvalue = d - 1;
+          col[plen] = threshold + 1;
+          break;
+        }
+      }
+      success = col[plen] <= threshold;
+    }
+    if (success)
+    {
+      report(info, s, maxlength);
+    }
+  }
+}
+
+typedef struct
+{
+  const orc_index *ix;
+  const uint8_t *p;
+  uint64_t m, q, *ecol;
+  orc_matches *out;
+} Directinfo;
+
+/* edistprocessstartpos, approxcompl.c:14-66 */
+static void directedit(void *info, uint64_t pos, uint64_t maxlength)
+{
+  Directinfo *di = (Directinfo *) info;
+  uint64_t len, dist;
+
+  longestmatch(di->p, di->m, di->ix->tis + pos, maxlength, di->ecol, &len,
+               &dist);
+  orc_push_match(di->out, len, pos, di->q, dist);
+}
+
+/* hammingprocessstartpos, approxcompl.c:68-83 */
+static void directhamming(void *info, uint64_t pos, uint64_t mm)
+{
+  Directinfo *di = (Directinfo *) info;
+
+  orc_push_match(di->out, di->m, pos, di->q, mm);
+}
+
+typedef struct
+{
+  Regions *rs;
+  uint64_t n, start, end;
+} Regioninfo;
+
+/* storeapmposition, splitesaapm.c:268-302 */
+static void regionhit(void *info, uint64_t s, uint64_t unused)
+{
+  Regioninfo *ri = (Regioninfo *) info;
+  const uint64_t lo = (ri->start > s) ? 0 : s - ri->start;
+  const uint64_t hi = (ri->end + s - 1 < ri->n) ? ri->end + s - 1 : ri->n - 1;
+
+  (void) unused;
+  pushregion(ri->rs, lo, hi);
+}
+
 int orc_findcompletematches(const orc_index *idx, const uint8_t *qbuf,
                             const uint64_t *qstart, const uint64_t *qlen,
                             uint64_t nq, orc_matches *out, char *err);
@@ -438,17 +622,52 @@ int orc_findapproxcompletematches(const orc_index *idx, const uint8_t *qbuf,
       break;
     }
     splitsize = orc_getoptsplit(doedist, 10, idx->numofchars, idx->n, m, k);
-    if (splitsize <= 1 || k / splitsize != 0)
+    if (splitsize <= 1)
     {
-      snprintf(err, 256, "approximate search with splitsize=%lu, "
-               "splitthreshold=%lu is not covered by the oracle",
-               (unsigned long) splitsize,
-               (unsigned long) (splitsize ? k / splitsize : 0));
-      rc = -4;
-      break;
+      /* splitesaapm.c:523-543: the whole pattern goes through esaapm /
+         esahamming, every reported suffix straight to the output function
+         (edistprocessstartpos / hammingprocessstartpos,
+         approxcompl.c:14-83): suffix array order */
+      Directinfo di;
+      di.ix = idx;
+      di.p = p;
+      di.m = m;
+      di.q = q;
+      di.ecol = ecol;
+      di.out = out;
+      if (doedist)
+      {
+        edithits(idx, p, m, k, directedit, &di);
+      } else
+      {
+        hamminghits(idx, p, m, k, directhamming, &di);
+      }
+      continue;
     }
     splitlen = m / splitsize;
     rs.n = 0;
+    if (k / splitsize != 0)
+    {
+      /* realsplitesaapm with a piece threshold: every piece through esaapm /
+         esahamming, every reported suffix into the region tree
+         (splitesaapm.c:400-425) */
+      Regioninfo ri;
+      ri.rs = &rs;
+      ri.n = idx->n;
+      for (poffset = 0; poffset < m - splitlen + 1; poffset += splitlen)
+      {
+        ri.start = doedist ? k + poffset : poffset;
+        ri.end = doedist ? m + k - poffset : m - poffset;
+        if (doedist)
+        {
+          edithits(idx, p + poffset, splitlen, k / splitsize, regionhit, &ri);
+        } else
+        {
+          hamminghits(idx, p + poffset, splitlen, k / splitsize, regionhit,
+                      &ri);
+        }
+      }
+    } else
     /* realsplitesaapm, splitesaapm.c:378-432 */
     for (poffset = 0; poffset < m - splitlen + 1; poffset += splitlen)
     {

@@ -312,6 +312,73 @@ def main():
     record(case, "tandem4", ["-tandem", "-l", "4", "db.fna"], wd)
     shutil.rmtree(wd)
 
+    # ---- 6b. short patterns with many errors: the configurations that reach
+    # esaapm / esahamming (Vmengine/splitesaapm.c:400-425, 523-543) -- pieces
+    # with a threshold of their own (K >= m/10) and patterns that are not cut
+    # at all (splitsize 1).  Reads of 8..32 bp against a repetitive 3-sequence
+    # text with wildcards.  The text ends in 64 wildcards: the reference's
+    # longest match (approxcompl.c:14-66 called with the width of the region,
+    # splitesaapm.c:96-105) reads up to m + K symbols from a start position
+    # without looking at the end of the mapped text, so that a match starting
+    # in the last m + K symbols depends on the bytes behind the file.
+    wd = tempfile.mkdtemp()
+    case = "c6"
+    rng = np.random.default_rng(20261004)
+    seqs = []
+    for s in range(3):
+        L = 16000
+        t = rng.integers(0, 4, L).astype(np.uint8)
+        unit = rng.integers(0, 4, 60).astype(np.uint8)
+        for r in range(25):
+            p = int(rng.integers(0, L - 60))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 3))):
+                u[int(rng.integers(0, 60))] = rng.integers(0, 4)
+            t[p:p + 60] = u
+        for r in range(3):
+            ln = int(rng.integers(15, 50))
+            a = int(rng.integers(0, L - ln))
+            t[a:a + ln] = np.resize(rng.integers(0, 4, int(rng.integers(1, 4))),
+                                    ln)
+        t[rng.random(L) < 0.001] = H.WILDCARD
+        seqs.append(t)
+    seqs[2][-64:] = H.WILDCARD     # nothing matches there
+    qs = []
+    for i in range(240):
+        s = seqs[int(rng.integers(0, 3))]
+        m = int(rng.integers(8, 33))
+        p = int(rng.integers(0, len(s) - 200))
+        q = s[p:p + m].copy()
+        if i % 11:
+            q[q == H.WILDCARD] = rng.integers(0, 4)
+        for e in range(int(rng.integers(0, 4))):
+            kind, x = int(rng.integers(0, 3)), int(rng.integers(0, len(q)))
+            if kind == 0:
+                q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4 if q[x] < 4 else 1
+            elif kind == 1 and len(q) > 8:
+                q = np.delete(q, x)
+            else:
+                q = np.insert(q, x, rng.integers(0, 4))
+        qs.append(q.astype(np.uint8))
+    H.write_fasta(wd + "/db.fna", [("s%d" % i, t) for i, t in enumerate(seqs)])
+    H.write_fasta(wd + "/reads.fna", [("r%d" % i, q) for i, q in
+                                      enumerate(qs)], width=1000)
+    gzcopy(wd + "/db.fna", GOLD + "/c6_db.fna.gz")
+    gzcopy(wd + "/reads.fna", GOLD + "/c6_reads.fna.gz")
+    manifest[case] = {"db": ["c6_db.fna.gz"], "query": "c6_reads.fna.gz",
+                      "runs": {}}
+    manifest[case]["index"] = index_case(
+        wd, "db.fna", ["-db", "db.fna", "-dna", "-pl", "-allout"])
+    for k in (1, 2, 3):
+        record(case, "approx_e%d" % k, ["-complete", "-e", str(k), "-q",
+                                        "reads.fna", "db.fna"], wd,
+               approx=True)
+    for k in (1, 2):
+        record(case, "approx_h%d" % k, ["-complete", "-h", str(k), "-q",
+                                        "reads.fna", "db.fna"], wd,
+               approx=True)
+    shutil.rmtree(wd)
+
     # ---- 7. the reference's tandem repeat test (src/Vmatch/Checktandem.sh):
     # index of src/testdata/at1MB built as src/bin/Makeindex.sh does, vmatch
     # -l 40 -tandem against the known answer src/Vmatch/Testdir/Tandem40AT

@@ -654,7 +654,7 @@ def _golden_fasta(name):
         return p
     out = os.path.join(_tempfile.gettempdir(),
                        "vsa_golden_%d_%s" % (os.getuid(), name[:-3]))
-    if not os.path.exists(out):
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(p):
         with _gzip.open(p, "rb") as f, open(out + ".tmp", "wb") as g:
             g.write(f.read())
         os.replace(out + ".tmp", out)

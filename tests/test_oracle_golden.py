@@ -214,3 +214,17 @@ def test_tandem_oracle_refuses_an_index_with_queries():
     with pytest.raises(H.OracleError) as ei:
         H.oracle_tandems(idx, 14)
     assert "does not allow query files in index" in str(ei.value)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="needs oracle/_ref (built where "
+                    "/root/reference exists)")
+def test_esaapm_restatement_against_the_live_reference():
+    """patterns that reach esaapm / esahamming (splitsize 1, piece thresholds
+    > 0): scripts/pin_esaapm_probe.py, a few rounds"""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable,
+                        os.path.join(H.ROOT, "scripts", "pin_esaapm_probe.py"),
+                        "11", "4"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"all 4 ok" in p.stdout, p.stdout.decode()
