@@ -314,12 +314,18 @@ int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   Errors: a threshold >= query length is the reference's
   "threshold=%lu>=%lu=patternlen not allowed" (splitesaapm.c:496-501): the
   matches of the queries before it are delivered, the return code is -2.
+  Patterns that are not cut (splitsize 1: short patterns -- reported in
+  suffix array order, splitesaapm.c:523-543) and pieces with a threshold of
+  their own (K >= m/10), i.e. what the reference hands to esaapm /
+  esahamming, and Hamming distance with a wildcard in a read take a general
+  path (a depth-first walk of the lcp-interval tree per piece,
+  approx_tree.inc) instead of the pigeonhole path; a batch with ONE such
+  query takes it as a whole.
   VSA_NOT_COVERED (-4), no result: the configuration is one this engine does
-  not implement (a piece threshold > 0 or a single piece, i.e. short patterns
-  with many errors; pieces shorter than prefixlength; alphabets beyond 4
-  symbols; m > 256; Hamming distance with special symbols in a query; a batch
-  mixing thresholds 0 and > 0) -- the caller keeps using its CPU function for
-  such batches (integration/vmengine_shim.c does).
+  not implement (alphabets beyond 4 symbols; m > 256; a batch mixing
+  thresholds 0 and > 0; texts of 2^32 symbols or more) -- the caller keeps
+  using its CPU function for such batches (integration/vmengine_shim.c
+  does).
 */
 #define VSA_NOT_COVERED (-4)
 int vsa_findapproxcompletematches(const vsa_index *index,

@@ -45,20 +45,28 @@ for rnd in range(rounds):
     big = rng.random() < 0.4
     doedist = rng.random() < 0.7
     k = int(rng.integers(1, 4))
-    m0 = int(rng.integers(40 * k + 30, 220))
+    short = rnd % 3 == 2     # esaapm / esahamming configurations
+    m0 = int(rng.integers(max(k + 3, 6), 34)) if short else \
+        int(rng.integers(40 * k + 30, 220))
     nreads = int(rng.integers(4200, 7000)) if big else int(rng.integers(100, 900))
+    if short:
+        nreads = int(rng.integers(30, 120))
     reads = []
     for i in range(nreads):
         m = m0 if uniform else int(rng.integers(max(40 * k + 30, m0 - 40),
                                                 m0 + 30))
+        if short and not uniform:
+            m = int(rng.integers(max(k + 3, 6), 34))
         p = int(rng.integers(0, len(tis) - m))
         q = tis[p:p + m].copy()
-        q[q >= H.WILDCARD] = rng.integers(0, 4)
+        q[q == H.SEPARATOR] = rng.integers(0, 4)
+        if not short or rng.random() < 0.8:
+            q[q >= H.WILDCARD] = rng.integers(0, 4)
         for e in range(int(rng.integers(0, k + 2))):
             kind, x = int(rng.integers(0, 3)), int(rng.integers(0, len(q)))
             if kind == 0 or not doedist or uniform:
                 q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4
-            elif kind == 1:
+            elif kind == 1 and len(q) > k + 3:
                 q = np.delete(q, x)
             else:
                 q = np.insert(q, x, rng.integers(0, 4))

@@ -33,19 +33,9 @@ def test_gpu_reproduces_reference_approximate_matches(V, case, key):
     doedist, k, pct = spec(key)
     gi = gpu_index(V, case)
     want = H.expected(case, key)
-    if not doedist and (q.symbols >= 254).any() and any(
-            (q.symbols[int(s):int(s + l)] >= 254).any()
-            for s, l in zip(q.start, q.length)):
-        # raw byte comparison in the reference (wildcards match each other):
-        # the engine declines the batch ...
-        with pytest.raises(V.VsaError) as ei:
-            V.findapproxcompletematches(gi, gpu_queries(V, q), False, k, pct)
-        assert ei.value.code == V.NOT_COVERED
-        # ... and answers the queries without special symbols
-        keep, q = without_special_queries(q)
-        newnum = np.cumsum(keep) - 1
-        want = want[keep[want["queryseq"].astype(np.int64)]]
-        want["queryseq"] = newnum[want["queryseq"].astype(np.int64)]
+    # (Hamming distance with wildcards in a read -- bytes are compared, a
+    # wildcard equals a wildcard -- and the short-pattern configurations of
+    # case c6 take the lcp-interval tree path, approx_tree.inc)
     got = V.findapproxcompletematches(gi, gpu_queries(V, q), doedist, k,
                                       pct).fetch()
     got = H.matches_as_ref(idx, got)
@@ -101,13 +91,7 @@ def test_gpu_equals_oracle_on_repeats_and_separators(V, doedist, qwild, m, k):
     t = gi.download()
     host = H.Index(len(tis), gi.info().prefixlength, 4, t["tis"], t["suf"],
                    t["lcp"], t["llv"], t["bck"], t["bwt"], None)
-    try:
-        want = H.oracle_approx(host, q, doedist, k)
-    except H.OracleNotCovered:
-        with pytest.raises(V.VsaError) as ei:
-            V.findapproxcompletematches(gi, gpu_queries(V, q), doedist, k)
-        assert ei.value.code == V.NOT_COVERED
-        return
+    want = H.oracle_approx(host, q, doedist, k)
     got = V.findapproxcompletematches(gi, gpu_queries(V, q), doedist,
                                       k).fetch()
     assert len(got) == len(want) and len(want) > 100
@@ -127,13 +111,19 @@ def test_threshold_not_below_pattern_length_is_the_reference_error(V):
                           H.oracle_approx(idx, first, True, 3))
 
 
-def test_uncovered_configurations_are_declined_not_guessed(V):
+def test_pieces_with_a_threshold_of_their_own(V):
     idx, q = H.load_case("c5")
     gi = gpu_index(V, "c5")
-    # 20 symbols with 3 errors: pieces would need a threshold of their own
+    # 20 symbols with 3 errors: three pieces of 6 with one error each
+    # (declined in round 1, the lcp-interval tree path since round 2)
     tiny = H.Queries.from_list([q.symbols[:20], q.symbols[160:180]])
+    got = V.findapproxcompletematches(gi, gpu_queries(V, tiny), True, 3)
+    assert np.array_equal(got.fetch(), H.oracle_approx(idx, tiny, True, 3))
+    # what neither path takes is still declined before any work: a batch that
+    # mixes threshold 0 (2 % of 20 symbols) with thresholds > 0
+    mixed = H.Queries.from_list([q.symbols[:20], q.symbols[150:300]])
     with pytest.raises(V.VsaError) as ei:
-        V.findapproxcompletematches(gi, gpu_queries(V, tiny), True, 3)
+        V.findapproxcompletematches(gi, gpu_queries(V, mixed), True, 2, True)
     assert ei.value.code == V.NOT_COVERED and ei.value.partial is None
 
 
@@ -196,3 +186,62 @@ def test_many_reads_of_different_lengths_are_planned_per_length(V):
                                           k).fetch()
         assert len(want) > 1000
         assert np.array_equal(got, want), (doedist, k)
+
+
+@pytest.mark.parametrize("doedist", [True, False])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_short_patterns_and_piece_thresholds_equal_the_oracle(V, doedist,
+                                                              seed):
+    """the configurations that reach esaapm / esahamming in the reference
+    (patterns that are not cut, pieces with a threshold of their own):
+    repetitive multi-sequence texts with wildcards, reads of 6..33 symbols
+    with up to K + 1 edit operations, some keeping a wildcard"""
+    rng = np.random.default_rng(100 * seed + int(doedist))
+    seqs = []
+    for s in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(3000, 12000))
+        t = rng.integers(0, 4, n).astype(np.uint8)
+        unit = rng.integers(0, 4, int(rng.integers(20, 80))).astype(np.uint8)
+        for r in range(int(rng.integers(0, 30))):
+            p = int(rng.integers(0, n - len(unit)))
+            u = unit.copy()
+            for e in range(int(rng.integers(0, 3))):
+                u[int(rng.integers(0, len(u)))] = rng.integers(0, 4)
+            t[p:p + len(u)] = u
+        for r in range(int(rng.integers(0, 3))):
+            ln = int(rng.integers(10, 60))
+            a = int(rng.integers(0, n - ln))
+            t[a:a + ln] = np.resize(rng.integers(0, 4, int(rng.integers(1, 4))),
+                                    ln)
+        t[rng.random(n) < 0.002] = H.WILDCARD
+        seqs.append(t)
+    tis = np.concatenate([np.concatenate([s, [H.SEPARATOR]])
+                          for s in seqs])[:-1].astype(np.uint8)
+    idx = H.oracle_build_index(tis, 4)
+    gi = V.Index.from_tables(idx.n, idx.prefixlength, 4, idx.tis, idx.suf,
+                             idx.lcp, idx.llv, idx.bck, idx.bwt)
+    for k in (1, 2, 3):
+        reads = []
+        for i in range(60):
+            m = int(rng.integers(max(k + 3, 6), 34))
+            p = int(rng.integers(0, len(tis) - m))
+            q = tis[p:p + m].copy()
+            q[q == H.SEPARATOR] = rng.integers(0, 4)
+            if rng.random() < 0.8:
+                q[q == H.WILDCARD] = rng.integers(0, 4)
+            for e in range(int(rng.integers(0, k + 2))):
+                kind, x = int(rng.integers(0, 3)), int(rng.integers(0, len(q)))
+                if kind == 0 or not doedist:
+                    q[x] = (q[x] + 1 + rng.integers(0, 3)) % 4 if q[x] < 4 \
+                        else 0
+                elif kind == 1 and len(q) > k + 3:
+                    q = np.delete(q, x)
+                else:
+                    q = np.insert(q, x, rng.integers(0, 4))
+            reads.append(q.astype(np.uint8))
+        hq = H.Queries.from_list(reads)
+        gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
+        want = H.oracle_approx(idx, hq, doedist, k)
+        got = V.findapproxcompletematches(gi, gq, doedist, k).fetch()
+        assert len(want) > 20
+        assert np.array_equal(got, want), (doedist, seed, k)

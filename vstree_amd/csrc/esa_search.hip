@@ -1652,6 +1652,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
 }
 
 #include "approx_search.inc"
+#include "approx_tree.inc"
 #include "selfmatch_search.inc"
 
 } // namespace
@@ -2331,11 +2332,11 @@ extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
   ApmPlan plan;
   int rc = apm_plan(index, queries, doedist != 0, distvalue, percent != 0,
                     plan);
-  if (rc != 0)
+  if (rc != 0 && rc != VSA_NOT_COVERED)
   {
     return rc;
   }
-  if (plan.allexact)
+  if (rc == 0 && plan.allexact)
   {
     // approxcompl.c:167-176: threshold 0 is the exact search
     return vsa_findcompletematches(index, queries, result);
@@ -2345,9 +2346,36 @@ extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
     return -100;
   }
   vsa_result *res = newresult(index->device);
-  rc = (index->isize == 4)
-           ? run_approx<uint32_t>(index, queries, doedist != 0, plan, res)
-           : run_approx<uint64_t>(index, queries, doedist != 0, plan, res);
+  if (rc == 0)
+  {
+    rc = (index->isize == 4)
+             ? run_approx<uint32_t>(index, queries, doedist != 0, plan, res)
+             : run_approx<uint64_t>(index, queries, doedist != 0, plan, res);
+  }
+  if (rc == VSA_NOT_COVERED)
+  {
+    // pieces with a threshold of their own, patterns that are not cut,
+    // Hamming distance with wildcards in a read: the reference's esaapm /
+    // esahamming configurations (approx_tree.inc)
+    TreePlan tplan;
+    vsa_result_free(res);
+    res = nullptr;
+    rc = apm_treeplan(index, queries, doedist != 0, distvalue, percent != 0,
+                      tplan);
+    if (rc != 0)
+    {
+      return rc;
+    }
+    res = newresult(index->device);
+    rc = (index->isize == 4)
+             ? run_approx_tree<uint32_t>(index, queries, doedist != 0, tplan,
+                                         res)
+             : run_approx_tree<uint64_t>(index, queries, doedist != 0, tplan,
+                                         res);
+    plan.qlimit = tplan.qlimit;
+    plan.failk = tplan.failk;
+    plan.failm = tplan.failm;
+  }
   if (rc != 0)
   {
     vsa_result_free(res);
