@@ -53,10 +53,11 @@ for rnd in range(rounds):
         nreads = int(rng.integers(30, 120))
     reads = []
     for i in range(nreads):
-        m = m0 if uniform else int(rng.integers(max(40 * k + 30, m0 - 40),
-                                                m0 + 30))
-        if short and not uniform:
-            m = int(rng.integers(max(k + 3, 6), 34))
+        if short:
+            m = m0 if uniform else int(rng.integers(max(k + 3, 6), 34))
+        else:
+            m = m0 if uniform else int(rng.integers(
+                max(40 * k + 30, m0 - 40), m0 + 30))
         p = int(rng.integers(0, len(tis) - m))
         q = tis[p:p + m].copy()
         q[q == H.SEPARATOR] = rng.integers(0, 4)
