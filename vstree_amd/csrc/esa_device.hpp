@@ -345,6 +345,169 @@ vsa_extend_packed(const DevIndex<uint32_t> &ix, uint64_t sufstart,
   return true;
 }
 
+// A whole query of up to 128 symbols at two bits per symbol in registers:
+// symbol 0 in the top two bits of w[0].  valid = the number of leading DNA
+// symbols (a wildcard ends it; <= the query's length).  Kernels whose
+// work-item is a query fetch the queries of a workgroup with coalesced loads
+// (vsa_pq_stage) instead of seven divergent 16-byte loads per lane, and every
+// later look at the query -- deep prefix, key, the comparison behind a key
+// tie -- is register arithmetic.
+struct PackedQuery
+{
+  uint64_t w[4];
+  uint32_t valid;
+};
+
+// symbols [at, at + 32) of pq, zeros behind symbol 127
+__device__ __forceinline__ uint64_t vsa_pq_window(const PackedQuery &pq,
+                                                  uint32_t at)
+{
+  const uint32_t i = at >> 5, sh = 2u * (at & 31u);
+  const uint64_t a = i == 0 ? pq.w[0]
+                            : (i == 1 ? pq.w[1]
+                                      : (i == 2 ? pq.w[2]
+                                                : (i == 3 ? pq.w[3] : 0))),
+                 b = i == 0 ? pq.w[1]
+                            : (i == 1 ? pq.w[2] : (i == 2 ? pq.w[3] : 0));
+  return sh != 0 ? (a << sh) | (b >> (64 - sh)) : a;
+}
+
+// The queries q0 .. q0 + BLK - 1 of a dense batch (every query m symbols, m a
+// multiple of 4, m <= 128; BLK * m a multiple of 16) through LDS: the
+// workgroup copies its BLK * m bytes with coalesced 16-byte loads, then every
+// lane packs its own query from LDS (row stride m/4 words: odd multiples of
+// four symbols are conflict free, m = 100 is).  lds: BLK * m bytes.  Must be
+// reached by all threads of the workgroup.
+template <int BLK>
+__device__ __forceinline__ void vsa_pq_stage(const DevQueries &qs, uint64_t q0,
+                                             uint32_t m, uint32_t *lds,
+                                             PackedQuery &pq)
+{
+  const uint64_t nhere = q0 < qs.nq ? (qs.nq - q0 < (uint64_t) BLK
+                                           ? qs.nq - q0
+                                           : (uint64_t) BLK)
+                                    : 0;
+  const uint32_t bytes = (uint32_t) nhere * m;
+  const uint8_t *src = qs.symbols + q0 * m;
+  for (uint32_t i = threadIdx.x; 16 * i < bytes; i += BLK)
+  {
+    // (the last piece may read up to 15 bytes of the next workgroup's
+    // queries or of the padding behind the batch)
+    const vsa_u128 v = vsa_load16(src + 16 * (uint64_t) i);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds) + i;
+    *dst = make_uint4((uint32_t) v.lo, (uint32_t) (v.lo >> 32),
+                      (uint32_t) v.hi, (uint32_t) (v.hi >> 32));
+  }
+  __syncthreads();
+  pq.w[0] = pq.w[1] = pq.w[2] = pq.w[3] = 0;
+  pq.valid = 0;
+  if (threadIdx.x < nhere)
+  {
+    const uint32_t *row = lds + threadIdx.x * (m >> 2);
+    uint32_t firstbad = m;
+#pragma unroll
+    for (uint32_t j = 0; j < 32; j++)
+    {
+      if (4 * j < m)
+      {
+        const uint32_t x = row[j];
+        const uint32_t bad = x & 0xFCFCFCFCu;
+        if (bad != 0 && firstbad == m)
+        {
+          firstbad = 4 * j + ((uint32_t) __builtin_ctz(bad) >> 3);
+        }
+        pq.w[j >> 3] |= (uint64_t) (vsa_pack4top(x) >> 24)
+                        << (56 - 8 * (j & 7));
+      }
+    }
+    pq.valid = firstbad;
+  }
+}
+
+// vsa_extend_packed for a query that is in registers already
+template <int CHUNKS>
+__device__ __forceinline__ bool
+vsa_extend_packed_pq(const DevIndex<uint32_t> &ix, uint64_t sufstart,
+                     const PackedQuery &pq, uint32_t pqoff,
+                     uint32_t querylen, uint32_t &lcplen)
+{
+  // the query suffix at offset pqoff of the packed query, querylen symbols
+  const uint32_t from = lcplen,
+                 left = pq.valid > pqoff ? pq.valid - pqoff : 0;
+  uint32_t l = lcplen, qeff = querylen < left ? querylen : left;
+  bool open = true;
+
+  if ((uint64_t) qeff > ix.n - sufstart)
+  {
+    qeff = (uint32_t) (ix.n - sufstart);
+  }
+  while (open && l < qeff)
+  {
+    uint64_t A[CHUNKS][2];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+    {
+      const uint32_t lc = l + 60u * (uint32_t) c;
+      A[c][0] = A[c][1] = 0;
+      if (c == 0 || lc < qeff)
+      {
+        const uint64_t pos = sufstart + lc;
+        const uint32_t sh = 2u * (uint32_t) (pos & 3u);
+        const vsa_u128 t = vsa_load16(ix.tis2 + (pos >> 2));
+        const uint64_t t0 = __builtin_bswap64(t.lo),
+                       t1 = __builtin_bswap64(t.hi);
+        A[c][0] = sh != 0 ? (t0 << sh) | (t1 >> (64 - sh)) : t0;
+        A[c][1] = t1 << sh;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+    {
+      if (open && l < qeff)
+      {
+        const uint64_t x0 = A[c][0] ^ vsa_pq_window(pq, pqoff + l),
+                       x1 = (A[c][1] ^ vsa_pq_window(pq, pqoff + l + 32)) &
+                            ~0xFFull;
+        uint32_t same = 60;
+        if (x0 != 0)
+        {
+          same = (uint32_t) __builtin_clzll(x0) >> 1;
+        } else if (x1 != 0)
+        {
+          same = 32 + ((uint32_t) __builtin_clzll(x1) >> 1);
+        }
+        l += same;
+        open = same == 60;
+      }
+    }
+  }
+  if (l > qeff)
+  {
+    l = qeff;
+  }
+  if (sufstart + l + 64 >= ix.firstspecial)
+  {
+    uint64_t b = (sufstart + from) >> 6;
+    const uint64_t blast = (sufstart + l) >> 6;
+    while (b <= blast)
+    {
+      uint32_t bits;
+      __builtin_memcpy(&bits, ix.spec64 + (b >> 3), 4);
+      bits >>= (uint32_t) (b & 7u);
+      const uint64_t have = 25, want = blast - b + 1;
+      const uint32_t mask = want >= have ? (1u << have) - 1u
+                                         : (1u << want) - 1u;
+      if ((bits & mask) != 0)
+      {
+        return false;
+      }
+      b += have;
+    }
+  }
+  lcplen = l;
+  return true;
+}
+
 // table accessors: esa8 carries suf and the lcp byte next to each other
 template <typename IDX, bool KEYED>
 __device__ __forceinline__ uint64_t vsa_sufstart(const DevIndex<IDX> &ix,
@@ -632,13 +795,17 @@ struct DeepHit
   bool notleftmax;  // see vsa_locate_deep, qleft
 };
 
-template <int AHEAD = 1, bool DEFER = false>
+template <int AHEAD = 1, bool DEFER = false, bool PQ = false>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
                 uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
-                uint32_t qleft = 0x100u)
+                uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
+                uint32_t pqoff = 0)
 {
+  // PQ: the whole query is in *pq (vsa_pq_stage / vsa_pq_load) and the
+  // suffix searched starts at its offset pqoff; `query` points at the bytes
+  // of that suffix for the lanes that fall back to them
   // qleft < 0x100 (MEM enumeration, needleft = the least length): the query
   // symbol in front of this suffix.  Only members of the deep bucket share D
   // or more symbols with the query; in a bucket of up to four their keys tell
@@ -659,30 +826,40 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
 
   if (active)
   {
-    // 32 query symbols as four 8-byte words (the buffer is padded)
-    const vsa_u128 qlo = vsa_load16(query), qhi = vsa_load16(query + 16);
-    const uint64_t w0 = qlo.lo, w1 = qlo.hi, w2 = qhi.lo, w3 = qhi.hi;
-    // this path exists for the DNA alphabet only (symbols 0..3): every other
-    // byte -- wildcard, separator -- ends the regular prefix
-    const uint64_t notdna = 0xFCFCFCFCFCFCFCFCull;
-    const uint64_t s0 = w0 & notdna, s1 = w1 & notdna, s2 = w2 & notdna,
-                   s3 = w3 & notdna;
     uint32_t valid = 32; // leading regular symbols inside the query
-    if ((s0 | s1 | s2 | s3) != 0)
+    uint64_t S = 0;      // its first 32 symbols, two bits each
+    if (PQ)
     {
-      if (s0 != 0)
+      const uint32_t left = pq->valid > pqoff ? pq->valid - pqoff : 0;
+      valid = left < 32 ? left : 32;
+      S = vsa_pq_window(*pq, pqoff);
+    } else
+    {
+      // 32 query symbols as four 8-byte words (the buffer is padded)
+      const vsa_u128 qlo = vsa_load16(query), qhi = vsa_load16(query + 16);
+      const uint64_t w0 = qlo.lo, w1 = qlo.hi, w2 = qhi.lo, w3 = qhi.hi;
+      // this path exists for the DNA alphabet only (symbols 0..3): every
+      // other byte -- wildcard, separator -- ends the regular prefix
+      const uint64_t notdna = 0xFCFCFCFCFCFCFCFCull;
+      const uint64_t s0 = w0 & notdna, s1 = w1 & notdna, s2 = w2 & notdna,
+                     s3 = w3 & notdna;
+      if ((s0 | s1 | s2 | s3) != 0)
       {
-        valid = (uint32_t) __builtin_ctzll(s0) >> 3;
-      } else if (s1 != 0)
-      {
-        valid = 8 + ((uint32_t) __builtin_ctzll(s1) >> 3);
-      } else if (s2 != 0)
-      {
-        valid = 16 + ((uint32_t) __builtin_ctzll(s2) >> 3);
-      } else
-      {
-        valid = 24 + ((uint32_t) __builtin_ctzll(s3) >> 3);
+        if (s0 != 0)
+        {
+          valid = (uint32_t) __builtin_ctzll(s0) >> 3;
+        } else if (s1 != 0)
+        {
+          valid = 8 + ((uint32_t) __builtin_ctzll(s1) >> 3);
+        } else if (s2 != 0)
+        {
+          valid = 16 + ((uint32_t) __builtin_ctzll(s2) >> 3);
+        } else
+        {
+          valid = 24 + ((uint32_t) __builtin_ctzll(s3) >> 3);
+        }
       }
+      S = ((uint64_t) vsa_pack16(w0, w1) << 32) | vsa_pack16(w2, w3);
     }
     if (valid > querylen)
     {
@@ -696,17 +873,6 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
       state = VSA_LOC_SLOW;
     } else
     {
-      const uint32_t shi = (vsa_pack4top((uint32_t) w0) & 0xFF000000u) |
-                           ((vsa_pack4top((uint32_t) (w0 >> 32)) >> 8) &
-                            0x00FF0000u) |
-                           ((vsa_pack4top((uint32_t) w1) >> 16) & 0xFF00u) |
-                           (vsa_pack4top((uint32_t) (w1 >> 32)) >> 24),
-                     slo = (vsa_pack4top((uint32_t) w2) & 0xFF000000u) |
-                           ((vsa_pack4top((uint32_t) (w2 >> 32)) >> 8) &
-                            0x00FF0000u) |
-                           ((vsa_pack4top((uint32_t) w3) >> 16) & 0xFF00u) |
-                           (vsa_pack4top((uint32_t) (w3 >> 32)) >> 24);
-      const uint64_t S = ((uint64_t) shi << 32) | slo;
       const uint64_t code = S >> (64 - 2 * D);
       qkey = (uint32_t) (S >> (64 - 2 * D - 2 * VSA_KEYSYMS)) & VSA_KEYMASK;
       limit = valid - D;
@@ -951,8 +1117,10 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     bool done = false;
     if (ix.tis2 != nullptr)
     {
-      done = vsa_extend_packed<(AHEAD > 1 ? 2 : 1)>(
-          ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
+      done = PQ ? vsa_extend_packed_pq<(AHEAD > 1 ? 2 : 1)>(
+                      ix, esucc & 0xFFFFFFFFull, *pq, pqoff, querylen, lcplen)
+                : vsa_extend_packed<(AHEAD > 1 ? 2 : 1)>(
+                      ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
     }
     if (!done)
     {

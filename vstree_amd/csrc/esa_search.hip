@@ -410,7 +410,16 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   tsearch.start();
   if constexpr (sizeof(IDX) == 4)
   {
-    if (ix.esa8 != nullptr)
+    const bool staged = ix.esa8 != nullptr && qs.dense != 0 &&
+                        qs.uniformlen <= 128 && (qs.uniformlen & 3u) == 0 &&
+                        qs.uniformlen >= ix.D && (index->tune & 128u) == 0;
+    if (staged)
+    {
+      k_complete_search<IDX, true, true>
+          <<<gridfor(qlimit), VSA_BLOCK, (size_t) VSA_BLOCK * qs.uniformlen,
+             stream>>>(ix, qs, qlimit, left.as<uint64_t>(),
+                       count.as<uint64_t>());
+    } else if (ix.esa8 != nullptr)
     {
       k_complete_search<IDX, true><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
           ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
@@ -998,10 +1007,26 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       {
         if constexpr (sizeof(IDX) == 4)
         {
-          k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-              ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
-              wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
-              wfmdb.as<uint64_t>());
+          // reads of one length m (a multiple of 4, <= 128), back to back:
+          // staged through LDS and packed (VSA_TUNE bit 7: without)
+          const bool staged = qs.dense != 0 && qs.uniformlen <= 128 &&
+                              (qs.uniformlen & 3u) == 0 &&
+                              (index->tune & 128u) == 0;
+          if (staged)
+          {
+            k_mum_first<IDX, true, true>
+                <<<gridfor(nq), VSA_BLOCK,
+                   (size_t) VSA_BLOCK * qs.uniformlen, stream>>>(
+                    ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+                    wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+                    wfmdb.as<uint64_t>());
+          } else
+          {
+            k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+                ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+                wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+                wfmdb.as<uint64_t>());
+          }
         }
       } else
       {
