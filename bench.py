@@ -20,7 +20,7 @@ sums the match counters.  `--mode selfmum` runs the other sharded path of
 SURVEY 8e instead: the self-index MUM scan split into suffix-array ranges.
 
 Prints ONE JSON line on rank 0.  Everything in it is measured in this run:
-  roofline           the dominant kernel (k_query_search), HIP-event time
+  roofline           the dominant kernel (k_query_search_planned), HIP-event time
   roofline_families  the same for the other kernel families of the path --
                      first pass, -complete (K1), MEM, -complete -e 2 (piece
                      search and banded alignment), the self-index scan (K3)
@@ -524,7 +524,7 @@ def main():
         traffic, traffic_source = (tj.get("hbm_bytes_per_launch"),
                                    tj.get("source"))
         out["roofline"] = {
-            "kernel": "k_query_search<uint32_t, MUM, deep, 256>",
+            "kernel": "k_query_search_planned<256>",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,

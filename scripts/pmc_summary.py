@@ -45,11 +45,15 @@ def main():
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:4]))
     if traffic:
-        dom = [k for k in sums if k.startswith("k_query_search")]
+        # the MUM search of the headline workload: the planned form since
+        # round 2 (mum_workplan.inc), the work-list form before
+        dom = ([k for k in sums if k.startswith("k_query_search_planned")] or
+               [k for k in sums if k.startswith("k_query_search<unsigned int, true")] or
+               [k for k in sums if k.startswith("k_query_search")])
         if dom:
             k = dom[0]
             mean = {c: sums[k][c] / launches[k][c] for c in sums[k]}
-            j = {"kernel": "k_query_search<uint32_t, MUM, deep, 256>",
+            j = {"kernel": k,
                  "index_bp": 3000000000, "queries": 10000000,
                  "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
                  "WRITE_SIZE_KiB": mean.get("WRITE_SIZE"),

@@ -953,7 +953,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist, wfirste,
       wfmlen, wfmdb, wfslot;
   uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
-  bool firstpass = false;
+  bool firstpass = false, fromplan = false;
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
@@ -1106,10 +1106,24 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       }
       plansearches = 2 * nlist;
     }
+    // planned MUM batch on the deep tables: the search kernel reads the
+    // plans itself (k_query_search_planned) -- no scan over the queries, no
+    // work list, no read-back of its length (VSA_TUNE bit 8: the list form)
+    if constexpr (sizeof(IDX) == 4)
+    {
+      fromplan = planned && domum && deepok && qblock == 0 &&
+                 (index->tune & 256u) == 0;
+    }
+    if (fromplan)
+    {
+      tanchor.stop();
+    }
     tb = 0;
     auto widen = rocprim::make_transform_iterator(
         wcount.as<uint32_t>(),
         [] __device__(uint32_t v) { return (uint64_t) v; });
+    if (!fromplan)
+    {
     VSA_HIP(rocprim::exclusive_scan(nullptr, tb, widen, wbase.as<uint64_t>(),
                                     (uint64_t) 0, (size_t) (nq + 1),
                                     rocprim::plus<uint64_t>(), stream));
@@ -1148,13 +1162,35 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     anchorms = tanchor.ms();
     dwlq = wlq.as<uint32_t>();
     dwloff = wloff.as<uint32_t>();
+    } // !fromplan
     res->stats.searches = nwork + nq + plansearches;
   }
-  if (dwlq == nullptr)
+  if (dwlq == nullptr && !fromplan)
   {
     firstpass = false; // the work reduction was not entered
   }
-  DevBuf doff, rawout, rawkeys, summary;
+  DevBuf doff, rawout, rawkeys, summary, blocksum, rtemp, rsum;
+  const uint64_t nplanblocks = (queries->nq + 255) / 256;
+  uint64_t plannedwork = 0;
+  size_t rbytes = 0;
+  if (fromplan)
+  {
+    // the work-items of the planned search: summed per workgroup by the
+    // kernel, reduced behind it, read back with the shard summary
+    if (blocksum.alloc((nplanblocks + 1) * 8) || rsum.alloc(8))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::reduce(nullptr, rbytes,
+                            blocksum.as<unsigned long long>(),
+                            rsum.as<unsigned long long>(), 0ull,
+                            (size_t) nplanblocks,
+                            rocprim::plus<unsigned long long>(), stream));
+    if (rtemp.alloc(rbytes))
+    {
+      return -100;
+    }
+  }
   if (cursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
       doff.alloc(nshards * 8) || summary.alloc(4 * 8))
   {
@@ -1293,7 +1329,16 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     if constexpr (sizeof(IDX) == 4)
     {
       deep = deep || deepok;
-      if (deep && nwork > 0)
+      if (fromplan)
+      {
+        k_query_search_planned<256>
+            <<<(unsigned int) nplanblocks, 256, 0, stream>>>(
+                ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+                wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
+                rawkeys.as<uint64_t>(), shardcap, nshards - 1,
+                cursor.as<unsigned long long>(), packbits, valbits,
+                blocksum.as<unsigned long long>());
+      } else if (deep && nwork > 0)
       {
         if (domum && defer)
         {
@@ -1349,6 +1394,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
 #undef VSA_LAUNCH_QUERY_B
     tsearch.stop();
     VSA_HIP(hipGetLastError());
+    if (fromplan)
+    {
+      VSA_HIP(rocprim::reduce(rtemp.p, rbytes,
+                              blocksum.as<unsigned long long>(),
+                              rsum.as<unsigned long long>(), 0ull,
+                              (size_t) nplanblocks,
+                              rocprim::plus<unsigned long long>(), stream));
+    }
     // where each region goes in the dense list, how much there is
     k_shard_summary<<<1, 1024, 0, stream>>>(
         cursor.as<unsigned long long>(), nshards, doff.as<uint64_t>(),
@@ -1357,18 +1410,20 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         summary.as<uint64_t>());
     VSA_HIP(hipGetLastError());
     {
-      const Fetch f[4] = {{summary.as<uint64_t>(), 8},
+      const Fetch f[5] = {{summary.as<uint64_t>(), 8},
                           {summary.as<uint64_t>() + 1, 8},
                           {summary.as<uint64_t>() + 2, 8},
-                          {summary.as<uint64_t>() + 3, 8}};
-      uint64_t got[4];
-      if (fetchwords(stream, f, 4, got))
+                          {summary.as<uint64_t>() + 3, 8},
+                          {fromplan ? rsum.p : summary.p, 8}};
+      uint64_t got[5];
+      if (fetchwords(stream, f, 5, got))
       {
         return -100;
       }
       needed = got[0];
       maxshard = got[1];
       nfirst = firstpass ? got[2] + (got[3] != 0 ? 1 : 0) : 0;
+      plannedwork = fromplan ? got[4] : 0;
     }
     searchms += tsearch.ms();
     if (maxshard <= shardcap)
@@ -1489,6 +1544,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   res->stats.search_kernel_ms = searchms;
   res->stats.anchor_ms = anchorms;
   res->stats.first_kernel_ms = tfirst.ms();
+  if (fromplan)
+  {
+    nwork = plannedwork;
+    res->stats.searches = nwork + queries->nq + plansearches;
+  }
   res->stats.kernel_searches = nwork;
   res->stats.total_device_ms = tall.ms();
   if (mumsum != ~0ull)
