@@ -1062,9 +1062,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       {
         return -100;
       }
-      k_plan_default<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-          wcount.as<uint32_t>(), nq, wplan.as<PlanRanges>());
-      VSA_HIP(hipGetLastError());
+      if (!firstpass)
+      {
+        // (after the first pass every query with work left is on the list
+        // and gets its plan from k_mum_plan; the others' are never used)
+        k_plan_default<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+            wcount.as<uint32_t>(), nq, wplan.as<PlanRanges>());
+        VSA_HIP(hipGetLastError());
+      }
       VSA_HIP(rocprim::select(nullptr, tb,
                               rocprim::counting_iterator<uint32_t>(0),
                               wlist.as<uint32_t>(), wnlist.as<uint64_t>(),
@@ -1108,11 +1113,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     // planned MUM batch on the deep tables: the search kernel reads the
     // plans itself (k_query_search_planned) -- no scan over the queries, no
-    // work list, no read-back of its length (VSA_TUNE bit 8: the list form)
+    // work list, no read-back of its length (a workgroup size in VSA_TUNE bits
+    // 8-19, e.g. VSA_TUNE=256, selects the list form)
     if constexpr (sizeof(IDX) == 4)
     {
-      fromplan = planned && domum && deepok && qblock == 0 &&
-                 (index->tune & 256u) == 0;
+      fromplan = planned && domum && deepok && qblock == 0;
     }
     if (fromplan)
     {

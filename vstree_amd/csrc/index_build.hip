@@ -20,7 +20,9 @@
 //   B5  k_bck_*          bucket boundaries (left, mid) from the sorted order
 //   B6  k_bwt            bwt[j] = tis[suf[j]-1]
 //
-// Limited to totallength + 1 < 2^32 in this round (32-bit suf on the device).
+// Every kernel is a template over the width of the tables (IDX = uint32_t for
+// totallength + 1 < 2^32, uint64_t above: include/types.h:41-61 of the
+// reference lifts the limit the same way, a 64-bit Uint).
 #include <cstring>
 #include <algorithm>
 #include <cmath>
@@ -71,10 +73,11 @@ inline unsigned int gridfor(uint64_t items)
 // The key holds H = 63/bits (at most) symbols, first symbol most significant;
 // from the first special on everything is zero, and bit 63 is set iff the key
 // contains a special: such keys are unique up to text position.
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
 k_pack_keys(const uint8_t *__restrict__ tis, uint64_t n, uint32_t numofchars,
             uint32_t bits, uint32_t H, uint64_t *__restrict__ keys,
-            uint32_t *__restrict__ sa)
+            IDX *__restrict__ sa)
 {
   const uint64_t i = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (i > n)
@@ -102,7 +105,7 @@ k_pack_keys(const uint8_t *__restrict__ tis, uint64_t n, uint32_t numofchars,
     key = (key << bits) | c;
   }
   keys[i] = key | (special ? (1ull << 63) : 0ull);
-  sa[i] = (uint32_t) i;
+  sa[i] = (IDX) i;
 }
 
 // Caution on bit 63: it must not take part in the ORDER (a key with a special
@@ -112,9 +115,10 @@ k_pack_keys(const uint8_t *__restrict__ tis, uint64_t n, uint32_t numofchars,
 // ---- B3: groups -----------------------------------------------------------
 
 // head[j] = j where a new group starts, else 0 (then max-scanned)
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
 k_initial_heads(const uint64_t *__restrict__ keys, uint64_t count,
-                uint32_t *__restrict__ head)
+                IDX *__restrict__ head)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (j >= count)
@@ -123,13 +127,13 @@ k_initial_heads(const uint64_t *__restrict__ keys, uint64_t count,
   }
   const uint64_t k = keys[j];
   const bool start = (j == 0) || (k >> 63) != 0 || keys[j - 1] != k;
-  head[j] = start ? (uint32_t) j : 0u;
+  head[j] = start ? (IDX) j : (IDX) 0;
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_scatter_rank(const uint32_t *__restrict__ sa,
-               const uint32_t *__restrict__ head, uint64_t count,
-               uint32_t *__restrict__ isa)
+k_scatter_rank(const IDX *__restrict__ sa, const IDX *__restrict__ head,
+               uint64_t count, IDX *__restrict__ isa)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (j < count)
@@ -139,8 +143,9 @@ k_scatter_rank(const uint32_t *__restrict__ sa,
 }
 
 // flag[j] = 1 iff j sits in a group of more than one suffix
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_flag_unresolved(const uint32_t *__restrict__ head, uint64_t count,
+k_flag_unresolved(const IDX *__restrict__ head, uint64_t count,
                   uint8_t *__restrict__ flag)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
@@ -148,39 +153,57 @@ k_flag_unresolved(const uint32_t *__restrict__ head, uint64_t count,
   {
     return;
   }
-  const bool tied = head[j] != (uint32_t) j ||
-                    (j + 1 < count && head[j + 1] == (uint32_t) j);
+  const bool tied = head[j] != (IDX) j ||
+                    (j + 1 < count && head[j + 1] == (IDX) j);
   flag[j] = tied ? 1 : 0;
 }
 
 // for the tied positions pos[r]: composite key (group head, rank of the
-// suffix h symbols further on) and the suffix itself
+// suffix h symbols further on) and the suffix itself.  The key takes
+// 2 * VB_RANKBITS bits: 64 for 32-bit tables, 80 (in a 128-bit word) for wide
+// ones.
+template <typename IDX>
+struct DoublingKey
+{
+  typedef uint64_t type;
+  static constexpr unsigned int rankbits = 32;
+};
+template <>
+struct DoublingKey<uint64_t>
+{
+  typedef rocprim::uint128_t type;
+  static constexpr unsigned int rankbits = 40;
+};
+
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_doubling_keys(const uint32_t *__restrict__ pos, uint64_t m,
-                const uint32_t *__restrict__ sa,
-                const uint32_t *__restrict__ head,
-                const uint32_t *__restrict__ isa, uint64_t h, uint64_t n,
-                uint64_t *__restrict__ ckey, uint32_t *__restrict__ csuf)
+k_doubling_keys(const IDX *__restrict__ pos, uint64_t m,
+                const IDX *__restrict__ sa, const IDX *__restrict__ head,
+                const IDX *__restrict__ isa, uint64_t h, uint64_t n,
+                typename DoublingKey<IDX>::type *__restrict__ ckey,
+                IDX *__restrict__ csuf)
 {
   const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (r >= m)
   {
     return;
   }
-  const uint32_t j = pos[r];
-  const uint32_t s = sa[j];
+  typedef typename DoublingKey<IDX>::type CK;
+  const IDX j = pos[r];
+  const IDX s = sa[j];
   // tied suffixes share h regular symbols, so s + h <= n
   const uint64_t next = (uint64_t) s + h;
-  const uint32_t second = isa[next <= n ? next : n];
-  ckey[r] = ((uint64_t) head[j] << 32) | second;
+  const IDX second = isa[next <= n ? next : n];
+  ckey[r] = ((CK) head[j] << DoublingKey<IDX>::rankbits) | (CK) second;
   csuf[r] = s;
 }
 
 // after sorting the tied suffixes by composite key: new group starts
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_doubling_heads(const uint64_t *__restrict__ ckey,
-                 const uint32_t *__restrict__ pos, uint64_t m,
-                 uint32_t *__restrict__ newhead)
+k_doubling_heads(const typename DoublingKey<IDX>::type *__restrict__ ckey,
+                 const IDX *__restrict__ pos, uint64_t m,
+                 IDX *__restrict__ newhead)
 {
   const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (r >= m)
@@ -188,32 +211,32 @@ k_doubling_heads(const uint64_t *__restrict__ ckey,
     return;
   }
   const bool start = (r == 0) || ckey[r - 1] != ckey[r];
-  newhead[r] = start ? pos[r] : 0u;
+  newhead[r] = start ? pos[r] : (IDX) 0;
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_doubling_writeback(const uint32_t *__restrict__ pos,
-                     const uint32_t *__restrict__ csuf,
-                     const uint32_t *__restrict__ newhead, uint64_t m,
-                     uint32_t *__restrict__ sa, uint32_t *__restrict__ head,
-                     uint32_t *__restrict__ isa)
+k_doubling_writeback(const IDX *__restrict__ pos, const IDX *__restrict__ csuf,
+                     const IDX *__restrict__ newhead, uint64_t m,
+                     IDX *__restrict__ sa, IDX *__restrict__ head,
+                     IDX *__restrict__ isa)
 {
   const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (r >= m)
   {
     return;
   }
-  const uint32_t j = pos[r], s = csuf[r], hd = newhead[r];
+  const IDX j = pos[r], s = csuf[r], hd = newhead[r];
   sa[j] = s;
   head[j] = hd;
   isa[s] = hd;
 }
 
 // among the previously tied positions: which are still tied
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_doubling_flags(const uint32_t *__restrict__ pos,
-                 const uint32_t *__restrict__ newhead, uint64_t m,
-                 uint8_t *__restrict__ flag)
+k_doubling_flags(const IDX *__restrict__ pos, const IDX *__restrict__ newhead,
+                 uint64_t m, uint8_t *__restrict__ flag)
 {
   const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (r >= m)
@@ -245,12 +268,13 @@ __device__ __forceinline__ uint64_t vb_extend(const uint8_t *__restrict__ tis,
   }
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
 k_lcp_chunks(const uint8_t *__restrict__ tis, uint64_t n,
-             const uint32_t *__restrict__ sa,
-             const uint32_t *__restrict__ isa, uint8_t *__restrict__ lcp,
-             uint32_t *__restrict__ llvidx, uint32_t *__restrict__ llvval,
-             uint64_t llvcap, unsigned long long *__restrict__ llvcount)
+             const IDX *__restrict__ sa, const IDX *__restrict__ isa,
+             uint8_t *__restrict__ lcp, IDX *__restrict__ llvidx,
+             IDX *__restrict__ llvval, uint64_t llvcap,
+             unsigned long long *__restrict__ llvcount)
 {
   const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   const uint64_t i0 = c * VB_LCP_CHUNK;
@@ -262,14 +286,14 @@ k_lcp_chunks(const uint8_t *__restrict__ tis, uint64_t n,
   uint64_t h = 0;
   for (uint64_t i = i0; i < i1; i++)
   {
-    const uint32_t r = isa[i];
+    const IDX r = isa[i];
     if (r == 0)
     {
       lcp[0] = 0;
       h = 0;
       continue;
     }
-    const uint32_t j = sa[r - 1];
+    const IDX j = sa[r - 1];
     h = vb_extend(tis, i, j, h);
     if (h < 255)
     {
@@ -281,7 +305,7 @@ k_lcp_chunks(const uint8_t *__restrict__ tis, uint64_t n,
       if (slot < llvcap)
       {
         llvidx[slot] = r;
-        llvval[slot] = (uint32_t) h;
+        llvval[slot] = (IDX) h;
       }
     }
     if (h > 0)
@@ -291,9 +315,10 @@ k_lcp_chunks(const uint8_t *__restrict__ tis, uint64_t n,
   }
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_llv_pairs(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ val,
-            uint64_t m, uint32_t *__restrict__ llv)
+k_llv_pairs(const IDX *__restrict__ idx, const IDX *__restrict__ val,
+            uint64_t m, IDX *__restrict__ llv)
 {
   const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (r < m)
@@ -332,24 +357,24 @@ __device__ __forceinline__ uint64_t vb_padcode(const uint8_t *__restrict__ tis,
   return c;
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_bck_init(uint32_t *__restrict__ left, uint32_t *__restrict__ mid,
-           uint64_t numofcodes)
+k_bck_init(IDX *__restrict__ left, IDX *__restrict__ mid, uint64_t numofcodes)
 {
   // grid-stride: 4^16 codes exceed the 2^32 work-items of one launch
   for (uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
        c < numofcodes; c += (uint64_t) gridDim.x * VB_BLOCK)
   {
-    left[c] = 0xFFFFFFFFu;
-    mid[c] = 0xFFFFFFFFu;
+    left[c] = ~(IDX) 0;
+    mid[c] = ~(IDX) 0;
   }
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
 k_bck_boundaries(const uint8_t *__restrict__ tis, uint64_t n,
-                 const uint32_t *__restrict__ sa, uint32_t pl,
-                 uint32_t numofchars, uint32_t *__restrict__ left,
-                 uint32_t *__restrict__ mid)
+                 const IDX *__restrict__ sa, uint32_t pl, uint32_t numofchars,
+                 IDX *__restrict__ left, IDX *__restrict__ mid)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (j > n)
@@ -365,27 +390,27 @@ k_bck_boundaries(const uint8_t *__restrict__ tis, uint64_t n,
   }
   if (j == 0 || prevcode != code)
   {
-    left[code] = (uint32_t) j;
+    left[code] = (IDX) j;
   }
   if (cut && (j == 0 || prevcode != code || !prevcut))
   {
-    mid[code] = (uint32_t) j;
+    mid[code] = (IDX) j;
   }
 }
 
 // left[] has been min-scanned from the right: empty buckets start where the
 // next occupied one starts.  A bucket without cut suffixes ends there, too.
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_bck_finish(const uint32_t *__restrict__ left,
-             const uint32_t *__restrict__ mid, uint64_t numofcodes,
-             uint32_t *__restrict__ bck)
+k_bck_finish(const IDX *__restrict__ left, const IDX *__restrict__ mid,
+             uint64_t numofcodes, IDX *__restrict__ bck)
 {
   for (uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
        c < numofcodes; c += (uint64_t) gridDim.x * VB_BLOCK)
   {
-    const uint32_t l = left[c];
-    uint32_t m = mid[c];
-    if (m == 0xFFFFFFFFu)
+    const IDX l = left[c];
+    IDX m = mid[c];
+    if (m == ~(IDX) 0)
     {
       // the last code always holds the end sentinel as a cut suffix, so c+1
       // exists whenever mid is unset
@@ -398,14 +423,15 @@ k_bck_finish(const uint32_t *__restrict__ left,
 
 // ---- B6: bwt --------------------------------------------------------------
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_bwt(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ sa,
-      uint64_t n, uint8_t *__restrict__ bwt)
+k_bwt(const uint8_t *__restrict__ tis, const IDX *__restrict__ sa, uint64_t n,
+      uint8_t *__restrict__ bwt)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (j <= n)
   {
-    const uint32_t s = sa[j];
+    const IDX s = sa[j];
     bwt[j] = (s > 0) ? tis[s - 1] : (uint8_t) VSA_UNDEFBWT;
   }
 }
@@ -431,7 +457,8 @@ uint32_t recommendedprefixlength(uint32_t numofchars, uint64_t totallength)
 
 struct MaxOp
 {
-  __device__ uint32_t operator()(uint32_t a, uint32_t b) const
+  template <typename T>
+  __device__ T operator()(T a, T b) const
   {
     return a > b ? a : b;
   }
@@ -439,13 +466,15 @@ struct MaxOp
 
 struct MinOp
 {
-  __device__ uint32_t operator()(uint32_t a, uint32_t b) const
+  template <typename T>
+  __device__ T operator()(T a, T b) const
   {
     return a < b ? a : b;
   }
 };
 
-int maxscan_inplace(uint32_t *data, uint64_t count, hipStream_t stream)
+template <typename IDX>
+int maxscan_inplace(IDX *data, uint64_t count, hipStream_t stream)
 {
   DevBuf temp;
   size_t tb = 0;
@@ -462,9 +491,13 @@ int maxscan_inplace(uint32_t *data, uint64_t count, hipStream_t stream)
 
 } // namespace
 
-int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
-                           uint32_t pl, uint32_t numofchars, uint32_t *out,
-                           hipStream_t stream)
+namespace
+{
+
+template <typename IDX>
+int build_bucket_table(const uint8_t *tis, uint64_t n, const IDX *sa,
+                       uint32_t pl, uint32_t numofchars, IDX *out,
+                       hipStream_t stream)
 {
   DevBuf left, mid, temp;
   vsa_dev_set_stream(stream);
@@ -474,22 +507,22 @@ int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
     nc *= numofchars;
   }
   const uint64_t count = n + 1;
-  if (left.alloc((nc + 1) * 4) || mid.alloc(nc * 4))
+  if (left.alloc((nc + 1) * sizeof(IDX)) || mid.alloc(nc * sizeof(IDX)))
   {
     return -100;
   }
   const unsigned int codegrid =
       (unsigned int) std::min<uint64_t>((nc + VB_BLOCK - 1) / VB_BLOCK,
                                         1u << 22);
-  k_bck_init<<<codegrid, VB_BLOCK, 0, stream>>>(
-      left.as<uint32_t>(), mid.as<uint32_t>(), nc);
+  k_bck_init<IDX><<<codegrid, VB_BLOCK, 0, stream>>>(
+      left.as<IDX>(), mid.as<IDX>(), nc);
   VSA_HIP(hipGetLastError());
-  k_bck_boundaries<<<gridfor(count), VB_BLOCK, 0, stream>>>(
-      tis, n, sa, pl, numofchars, left.as<uint32_t>(), mid.as<uint32_t>());
+  k_bck_boundaries<IDX><<<gridfor(count), VB_BLOCK, 0, stream>>>(
+      tis, n, sa, pl, numofchars, left.as<IDX>(), mid.as<IDX>());
   VSA_HIP(hipGetLastError());
   // suffix-min over the codes = inclusive min-scan on the reversed array
   size_t tb = 0;
-  auto rin = rocprim::make_reverse_iterator(left.as<uint32_t>() + nc);
+  auto rin = rocprim::make_reverse_iterator(left.as<IDX>() + nc);
   VSA_HIP(rocprim::inclusive_scan(nullptr, tb, rin, rin, (size_t) nc, MinOp(),
                                   stream));
   if (temp.alloc(tb))
@@ -498,23 +531,41 @@ int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
   }
   VSA_HIP(rocprim::inclusive_scan(temp.p, tb, rin, rin, (size_t) nc, MinOp(),
                                   stream));
-  k_bck_finish<<<codegrid, VB_BLOCK, 0, stream>>>(
-      left.as<uint32_t>(), mid.as<uint32_t>(), nc, out);
+  k_bck_finish<IDX><<<codegrid, VB_BLOCK, 0, stream>>>(
+      left.as<IDX>(), mid.as<IDX>(), nc, out);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(stream));
   return 0;
 }
 
+} // namespace
+
+int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
+                           uint32_t pl, uint32_t numofchars, uint32_t *out,
+                           hipStream_t stream)
+{
+  return build_bucket_table<uint32_t>(tis, n, sa, pl, numofchars, out, stream);
+}
+
+int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint64_t *sa,
+                           uint32_t pl, uint32_t numofchars, uint64_t *out,
+                           hipStream_t stream)
+{
+  return build_bucket_table<uint64_t>(tis, n, sa, pl, numofchars, out, stream);
+}
+
 namespace
 {
 
+template <typename IDX>
 int build_tables(vsa_index *ix)
 {
+  typedef typename DoublingKey<IDX>::type CK;
   hipStream_t stream = ix->stream;
   vsa_dev_set_stream(stream);
   const uint64_t n = ix->n, count = n + 1;
   const uint8_t *tis = ix->tis_alloc + VSA_TIS_FRONTPAD;
-  uint32_t *sa = (uint32_t *) ix->suf;
+  IDX *sa = (IDX *) ix->suf;
   uint32_t bits = 1;
   while ((1u << bits) < ix->numofchars + 1)
   {
@@ -527,42 +578,42 @@ int build_tables(vsa_index *ix)
   {
     DevBuf keys, keys2, sa2, temp;
     if (keys.alloc(count * 8) || keys2.alloc(count * 8) ||
-        sa2.alloc(count * 4))
+        sa2.alloc(count * sizeof(IDX)))
     {
       return -100;
     }
-    k_pack_keys<<<gridfor(count), VB_BLOCK, 0, stream>>>(
+    k_pack_keys<IDX><<<gridfor(count), VB_BLOCK, 0, stream>>>(
         tis, n, ix->numofchars, bits, H, keys.as<uint64_t>(),
-        sa2.as<uint32_t>());
+        sa2.as<IDX>());
     VSA_HIP(hipGetLastError());
     size_t tb = 0;
     VSA_HIP(rocprim::radix_sort_pairs(
         nullptr, tb, keys.as<uint64_t>(), keys2.as<uint64_t>(),
-        sa2.as<uint32_t>(), sa, (size_t) count, 0u, H * bits, stream));
+        sa2.as<IDX>(), sa, (size_t) count, 0u, H * bits, stream));
     if (temp.alloc(tb))
     {
       return -100;
     }
     VSA_HIP(rocprim::radix_sort_pairs(
         temp.p, tb, keys.as<uint64_t>(), keys2.as<uint64_t>(),
-        sa2.as<uint32_t>(), sa, (size_t) count, 0u, H * bits, stream));
+        sa2.as<IDX>(), sa, (size_t) count, 0u, H * bits, stream));
     temp.free();
     keys.free();
     sa2.free();
-    if (isa.alloc(count * 4) || head.alloc(count * 4))
+    if (isa.alloc(count * sizeof(IDX)) || head.alloc(count * sizeof(IDX)))
     {
       return -100;
     }
-    k_initial_heads<<<gridfor(count), VB_BLOCK, 0, stream>>>(
-        keys2.as<uint64_t>(), count, head.as<uint32_t>());
+    k_initial_heads<IDX><<<gridfor(count), VB_BLOCK, 0, stream>>>(
+        keys2.as<uint64_t>(), count, head.as<IDX>());
     VSA_HIP(hipGetLastError());
   }
-  if (maxscan_inplace(head.as<uint32_t>(), count, stream))
+  if (maxscan_inplace(head.as<IDX>(), count, stream))
   {
     return -100;
   }
-  k_scatter_rank<<<gridfor(count), VB_BLOCK, 0, stream>>>(
-      sa, head.as<uint32_t>(), count, isa.as<uint32_t>());
+  k_scatter_rank<IDX><<<gridfor(count), VB_BLOCK, 0, stream>>>(
+      sa, head.as<IDX>(), count, isa.as<IDX>());
   VSA_HIP(hipGetLastError());
 
   // B3: positions still tied, refined until none is left
@@ -573,25 +624,25 @@ int build_tables(vsa_index *ix)
     {
       return -100;
     }
-    k_flag_unresolved<<<gridfor(count), VB_BLOCK, 0, stream>>>(
-        head.as<uint32_t>(), count, flag.as<uint8_t>());
+    k_flag_unresolved<IDX><<<gridfor(count), VB_BLOCK, 0, stream>>>(
+        head.as<IDX>(), count, flag.as<uint8_t>());
     VSA_HIP(hipGetLastError());
-    if (pos.alloc(count * 4))
+    if (pos.alloc(count * sizeof(IDX)))
     {
       return -100;
     }
     {
       size_t tb = 0;
-      auto counting = rocprim::counting_iterator<uint32_t>(0);
+      auto counting = rocprim::counting_iterator<IDX>(0);
       VSA_HIP(rocprim::select(nullptr, tb, counting, flag.as<uint8_t>(),
-                              pos.as<uint32_t>(), dcount.as<uint64_t>(),
+                              pos.as<IDX>(), dcount.as<uint64_t>(),
                               (size_t) count, stream));
       if (temp.alloc(tb))
       {
         return -100;
       }
       VSA_HIP(rocprim::select(temp.p, tb, counting, flag.as<uint8_t>(),
-                              pos.as<uint32_t>(), dcount.as<uint64_t>(),
+                              pos.as<IDX>(), dcount.as<uint64_t>(),
                               (size_t) count, stream));
       VSA_HIP(hipMemcpyAsync(&m, dcount.p, 8, hipMemcpyDeviceToHost, stream));
       VSA_HIP(hipStreamSynchronize(stream));
@@ -601,63 +652,64 @@ int build_tables(vsa_index *ix)
     while (m > 0)
     {
       DevBuf ckey, ckey2, csuf, csuf2, newhead, rflag, pos2, t2;
-      if (ckey.alloc(m * 8) || ckey2.alloc(m * 8) || csuf.alloc(m * 4) ||
-          csuf2.alloc(m * 4) || newhead.alloc(m * 4) || rflag.alloc(m) ||
-          pos2.alloc(m * 4))
+      if (ckey.alloc(m * sizeof(CK)) || ckey2.alloc(m * sizeof(CK)) ||
+          csuf.alloc(m * sizeof(IDX)) || csuf2.alloc(m * sizeof(IDX)) ||
+          newhead.alloc(m * sizeof(IDX)) || rflag.alloc(m) ||
+          pos2.alloc(m * sizeof(IDX)))
       {
         return -100;
       }
-      k_doubling_keys<<<gridfor(m), VB_BLOCK, 0, stream>>>(
-          pos.as<uint32_t>(), m, sa, head.as<uint32_t>(), isa.as<uint32_t>(),
-          h, n, ckey.as<uint64_t>(), csuf.as<uint32_t>());
+      k_doubling_keys<IDX><<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          pos.as<IDX>(), m, sa, head.as<IDX>(), isa.as<IDX>(),
+          h, n, ckey.as<CK>(), csuf.as<IDX>());
       VSA_HIP(hipGetLastError());
       size_t tb = 0;
       VSA_HIP(rocprim::radix_sort_pairs(
-          nullptr, tb, ckey.as<uint64_t>(), ckey2.as<uint64_t>(),
-          csuf.as<uint32_t>(), csuf2.as<uint32_t>(), (size_t) m, 0u, 64u,
-          stream));
+          nullptr, tb, ckey.as<CK>(), ckey2.as<CK>(),
+          csuf.as<IDX>(), csuf2.as<IDX>(), (size_t) m, 0u,
+          2 * DoublingKey<IDX>::rankbits, stream));
       if (t2.alloc(tb))
       {
         return -100;
       }
       VSA_HIP(rocprim::radix_sort_pairs(
-          t2.p, tb, ckey.as<uint64_t>(), ckey2.as<uint64_t>(),
-          csuf.as<uint32_t>(), csuf2.as<uint32_t>(), (size_t) m, 0u, 64u,
-          stream));
-      k_doubling_heads<<<gridfor(m), VB_BLOCK, 0, stream>>>(
-          ckey2.as<uint64_t>(), pos.as<uint32_t>(), m,
-          newhead.as<uint32_t>());
+          t2.p, tb, ckey.as<CK>(), ckey2.as<CK>(),
+          csuf.as<IDX>(), csuf2.as<IDX>(), (size_t) m, 0u,
+          2 * DoublingKey<IDX>::rankbits, stream));
+      k_doubling_heads<IDX><<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          ckey2.as<CK>(), pos.as<IDX>(), m,
+          newhead.as<IDX>());
       VSA_HIP(hipGetLastError());
-      if (maxscan_inplace(newhead.as<uint32_t>(), m, stream))
+      if (maxscan_inplace(newhead.as<IDX>(), m, stream))
       {
         return -100;
       }
-      k_doubling_writeback<<<gridfor(m), VB_BLOCK, 0, stream>>>(
-          pos.as<uint32_t>(), csuf2.as<uint32_t>(), newhead.as<uint32_t>(), m,
-          sa, head.as<uint32_t>(), isa.as<uint32_t>());
+      k_doubling_writeback<IDX><<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          pos.as<IDX>(), csuf2.as<IDX>(), newhead.as<IDX>(), m,
+          sa, head.as<IDX>(), isa.as<IDX>());
       VSA_HIP(hipGetLastError());
-      k_doubling_flags<<<gridfor(m), VB_BLOCK, 0, stream>>>(
-          pos.as<uint32_t>(), newhead.as<uint32_t>(), m,
+      k_doubling_flags<IDX><<<gridfor(m), VB_BLOCK, 0, stream>>>(
+          pos.as<IDX>(), newhead.as<IDX>(), m,
           rflag.as<uint8_t>());
       VSA_HIP(hipGetLastError());
       uint64_t m2 = 0;
       tb = 0;
-      VSA_HIP(rocprim::select(nullptr, tb, pos.as<uint32_t>(),
-                              rflag.as<uint8_t>(), pos2.as<uint32_t>(),
+      VSA_HIP(rocprim::select(nullptr, tb, pos.as<IDX>(),
+                              rflag.as<uint8_t>(), pos2.as<IDX>(),
                               dcount.as<uint64_t>(), (size_t) m, stream));
       if (t2.alloc(tb))
       {
         return -100;
       }
-      VSA_HIP(rocprim::select(t2.p, tb, pos.as<uint32_t>(),
-                              rflag.as<uint8_t>(), pos2.as<uint32_t>(),
+      VSA_HIP(rocprim::select(t2.p, tb, pos.as<IDX>(),
+                              rflag.as<uint8_t>(), pos2.as<IDX>(),
                               dcount.as<uint64_t>(), (size_t) m, stream));
       VSA_HIP(hipMemcpyAsync(&m2, dcount.p, 8, hipMemcpyDeviceToHost,
                              stream));
       VSA_HIP(hipStreamSynchronize(stream));
       if (m2 > 0)
       {
-        VSA_HIP(hipMemcpyAsync(pos.p, pos2.p, m2 * 4,
+        VSA_HIP(hipMemcpyAsync(pos.p, pos2.p, m2 * sizeof(IDX),
                                hipMemcpyDeviceToDevice, stream));
         VSA_HIP(hipStreamSynchronize(stream));
       }
@@ -682,15 +734,16 @@ int build_tables(vsa_index *ix)
     }
     for (int attempt = 0; attempt < 2; attempt++)
     {
-      if (llvidx.alloc(llvcap * 4) || llvval.alloc(llvcap * 4))
+      if (llvidx.alloc(llvcap * sizeof(IDX)) ||
+          llvval.alloc(llvcap * sizeof(IDX)))
       {
         return -100;
       }
       VSA_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
       const uint64_t chunks = (count + VB_LCP_CHUNK - 1) / VB_LCP_CHUNK;
-      k_lcp_chunks<<<gridfor(chunks), VB_BLOCK, 0, stream>>>(
-          tis, n, sa, isa.as<uint32_t>(), ix->lcp, llvidx.as<uint32_t>(),
-          llvval.as<uint32_t>(), llvcap,
+      k_lcp_chunks<IDX><<<gridfor(chunks), VB_BLOCK, 0, stream>>>(
+          tis, n, sa, isa.as<IDX>(), ix->lcp, llvidx.as<IDX>(),
+          llvval.as<IDX>(), llvcap,
           cnt.as<unsigned long long>());
       VSA_HIP(hipGetLastError());
       VSA_HIP(hipMemcpyAsync(&needed, cnt.p, 8, hipMemcpyDeviceToHost,
@@ -706,39 +759,39 @@ int build_tables(vsa_index *ix)
     ix->nllv = needed;
     (void) hipFree(ix->llv);
     ix->llv = nullptr;
-    VSA_HIP(vsa_hip_malloc(&ix->llv, 2 * needed * 4 + 16));
-    ix->device_bytes += 2 * needed * 4;
+    VSA_HIP(vsa_hip_malloc(&ix->llv, 2 * needed * sizeof(IDX) + 16));
+    ix->device_bytes += 2 * needed * sizeof(IDX);
     if (needed > 0)
     {
       // exceptions sorted by index (Mkvtree/bese.c:557-566 emits them so)
-      if (sidx.alloc(needed * 4) || sval.alloc(needed * 4))
+      if (sidx.alloc(needed * sizeof(IDX)) || sval.alloc(needed * sizeof(IDX)))
       {
         return -100;
       }
       size_t tb = 0;
       VSA_HIP(rocprim::radix_sort_pairs(
-          nullptr, tb, llvidx.as<uint32_t>(), sidx.as<uint32_t>(),
-          llvval.as<uint32_t>(), sval.as<uint32_t>(), (size_t) needed, 0u,
-          32u, stream));
+          nullptr, tb, llvidx.as<IDX>(), sidx.as<IDX>(),
+          llvval.as<IDX>(), sval.as<IDX>(), (size_t) needed, 0u,
+          (unsigned int) (8 * sizeof(IDX)), stream));
       if (temp.alloc(tb))
       {
         return -100;
       }
       VSA_HIP(rocprim::radix_sort_pairs(
-          temp.p, tb, llvidx.as<uint32_t>(), sidx.as<uint32_t>(),
-          llvval.as<uint32_t>(), sval.as<uint32_t>(), (size_t) needed, 0u,
-          32u, stream));
-      k_llv_pairs<<<gridfor(needed), VB_BLOCK, 0, stream>>>(
-          sidx.as<uint32_t>(), sval.as<uint32_t>(), needed,
-          (uint32_t *) ix->llv);
+          temp.p, tb, llvidx.as<IDX>(), sidx.as<IDX>(),
+          llvval.as<IDX>(), sval.as<IDX>(), (size_t) needed, 0u,
+          (unsigned int) (8 * sizeof(IDX)), stream));
+      k_llv_pairs<IDX><<<gridfor(needed), VB_BLOCK, 0, stream>>>(
+          sidx.as<IDX>(), sval.as<IDX>(), needed,
+          (IDX *) ix->llv);
       VSA_HIP(hipGetLastError());
       VSA_HIP(hipStreamSynchronize(stream));
     }
   }
 
   // B5: bck
-  if (vsa_build_bucket_table(tis, n, sa, ix->pl, ix->numofchars,
-                             (uint32_t *) ix->bck, stream))
+  if (build_bucket_table<IDX>(tis, n, sa, ix->pl, ix->numofchars,
+                              (IDX *) ix->bck, stream))
   {
     return -100;
   }
@@ -746,7 +799,7 @@ int build_tables(vsa_index *ix)
   // B6: bwt
   if (ix->bwt != nullptr)
   {
-    k_bwt<<<gridfor(count), VB_BLOCK, 0, stream>>>(tis, sa, n, ix->bwt);
+    k_bwt<IDX><<<gridfor(count), VB_BLOCK, 0, stream>>>(tis, sa, n, ix->bwt);
     VSA_HIP(hipGetLastError());
   }
   VSA_HIP(hipStreamSynchronize(stream));
@@ -768,10 +821,11 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
     VSA_ERROR("numofchars=%u is not a usable alphabet size", numofchars);
     return -2;
   }
-  if (totallength + 1 >= 0xFFFFFFFFull)
+  if (totallength + 1 >= (1ull << DoublingKey<uint64_t>::rankbits))
   {
     VSA_ERROR("totallength=%lu: the GPU index builder handles texts below "
-              "2^32 symbols", (unsigned long) totallength);
+              "2^%u symbols", (unsigned long) totallength,
+              DoublingKey<uint64_t>::rankbits);
     return -3;
   }
   if (prefixlength == 0)
@@ -785,8 +839,9 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
     return -4;
   }
   vsa_index *ix = nullptr;
+  // (VSA_FORCE_WIDE=1 builds 64-bit tables for a short text, too)
   int rc = vsa_index_alloc(totallength, prefixlength, numofchars, 0, true,
-                           device, &ix, false);
+                           device, &ix, true);
   if (rc != 0)
   {
     vsa_index_close(ix);
@@ -803,7 +858,8 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
       return -100;
     }
   }
-  rc = build_tables(ix);
+  rc = ix->isize == 4 ? build_tables<uint32_t>(ix)
+                      : build_tables<uint64_t>(ix);
   if (rc == 0)
   {
     rc = vsa_index_make_esa8(ix);
@@ -823,21 +879,22 @@ int build_common(const void *src, bool srcondevice, uint64_t totallength,
 
 // runstart[j] = j where lcp[j] < prefixlength (a new bucket run starts), else
 // 0; after a max-scan sti1[suf[j]] = min(255, j - runstart[j])
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
 k_sti1_runstarts(const uint8_t *__restrict__ lcp, uint64_t count, uint32_t pl,
-                 uint32_t *__restrict__ runstart)
+                 IDX *__restrict__ runstart)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (j < count)
   {
-    runstart[j] = (j == 0 || lcp[j] < (uint8_t) pl) ? (uint32_t) j : 0u;
+    runstart[j] = (j == 0 || lcp[j] < (uint8_t) pl) ? (IDX) j : (IDX) 0;
   }
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(VB_BLOCK)
-k_sti1_scatter(const uint32_t *__restrict__ sa,
-               const uint32_t *__restrict__ runstart, uint64_t count,
-               uint8_t *__restrict__ sti1)
+k_sti1_scatter(const IDX *__restrict__ sa, const IDX *__restrict__ runstart,
+               uint64_t count, uint8_t *__restrict__ sti1)
 {
   const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
   if (j < count)
@@ -847,6 +904,36 @@ k_sti1_scatter(const uint32_t *__restrict__ sa,
   }
 }
 
+namespace
+{
+
+template <typename IDX>
+int make_sti1(const vsa_index *ix, uint8_t *sti1)
+{
+  const uint64_t count = ix->n + 1;
+  DevBuf runstart, out;
+  vsa_dev_set_stream(ix->stream);
+  if (runstart.alloc(count * sizeof(IDX)) || out.alloc(count))
+  {
+    return -100;
+  }
+  k_sti1_runstarts<IDX><<<gridfor(count), VB_BLOCK, 0, ix->stream>>>(
+      ix->lcp, count, ix->pl, runstart.as<IDX>());
+  VSA_HIP(hipGetLastError());
+  if (maxscan_inplace(runstart.as<IDX>(), count, ix->stream))
+  {
+    return -100;
+  }
+  k_sti1_scatter<IDX><<<gridfor(count), VB_BLOCK, 0, ix->stream>>>(
+      (const IDX *) ix->suf, runstart.as<IDX>(), count, out.as<uint8_t>());
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipStreamSynchronize(ix->stream));
+  VSA_HIP(hipMemcpy(sti1, out.p, count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+} // namespace
+
 extern "C" int vsa_index_make_sti1(const vsa_index *ix, uint8_t *sti1)
 {
   if (ix == nullptr || sti1 == nullptr)
@@ -854,36 +941,12 @@ extern "C" int vsa_index_make_sti1(const vsa_index *ix, uint8_t *sti1)
     VSA_ERROR("vsa_index_make_sti1: NULL argument");
     return -1;
   }
-  if (ix->isize != 4)
-  {
-    VSA_ERROR("vsa_index_make_sti1: 64-bit device tables are not supported");
-    return -2;
-  }
   if (vsa_set_device(ix->device) != 0)
   {
     return -100;
   }
-  const uint64_t count = ix->n + 1;
-  DevBuf runstart, out;
-  vsa_dev_set_stream(ix->stream);
-  if (runstart.alloc(count * 4) || out.alloc(count))
-  {
-    return -100;
-  }
-  k_sti1_runstarts<<<gridfor(count), VB_BLOCK, 0, ix->stream>>>(
-      ix->lcp, count, ix->pl, runstart.as<uint32_t>());
-  VSA_HIP(hipGetLastError());
-  if (maxscan_inplace(runstart.as<uint32_t>(), count, ix->stream))
-  {
-    return -100;
-  }
-  k_sti1_scatter<<<gridfor(count), VB_BLOCK, 0, ix->stream>>>(
-      (const uint32_t *) ix->suf, runstart.as<uint32_t>(), count,
-      out.as<uint8_t>());
-  VSA_HIP(hipGetLastError());
-  VSA_HIP(hipStreamSynchronize(ix->stream));
-  VSA_HIP(hipMemcpy(sti1, out.p, count, hipMemcpyDeviceToHost));
-  return 0;
+  return ix->isize == 4 ? make_sti1<uint32_t>(ix, sti1)
+                        : make_sti1<uint64_t>(ix, sti1);
 }
 
 extern "C" int vsa_index_build(const uint8_t *tis, uint64_t totallength,

@@ -230,6 +230,9 @@ int vsa_index_make_esa8(vsa_index *ix);
 int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint32_t *sa,
                            uint32_t pl, uint32_t numofchars, uint32_t *out,
                            hipStream_t stream);
+int vsa_build_bucket_table(const uint8_t *tis, uint64_t n, const uint64_t *sa,
+                           uint32_t pl, uint32_t numofchars, uint64_t *out,
+                           hipStream_t stream);
 
 // device tables of the given shape, contents undefined (api.hip)
 // mayforcewide: VSA_FORCE_WIDE=1 may make the tables 64 bits wide (uploads of
