@@ -95,6 +95,9 @@ typedef struct
   uint64_t totallength, numofcodes, largelcpvalues, device_bytes;
   uint32_t prefixlength, numofchars, device_integersize;
   int device, hasindexedqueries, hasbwt;
+  /* symbols of the derived deep bucket table (esa8/slot16), 0 if
+     this index has none and is searched probe for probe like the reference */
+  uint32_t deepprefix;
 } vsa_index_info;
 
 int vsa_index_getinfo(const vsa_index *index, vsa_index_info *info);

@@ -102,3 +102,55 @@ def test_search_on_built_index_equals_golden(V):
     got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
                                                    mum=True).fetch())
     assert np.array_equal(got, H.expected("c1", "mum20"))
+
+
+# ---- wide tables (n + 1 >= 2^32 in production; forced here) -----------------
+
+def test_wide_builder_writes_the_same_tables(V, monkeypatch):
+    """VSA_FORCE_WIDE=1: the 64-bit instantiation of the builder (prefix
+    doubling on 80-bit composite keys) and of the deep-table kernels, on the
+    golden texts and on the seeded ones above"""
+    monkeypatch.setenv("VSA_FORCE_WIDE", "1")
+    for case in ("c1", "grumbach", "wildcards"):
+        idx, _ = H.load_case(case)
+        gi = V.Index.build(idx.tis, 4, idx.prefixlength)
+        info = gi.info()
+        assert info.device_integersize == 64 and info.deepprefix > 0
+        got = md5s(gi.download())
+        assert got == {k: M[case]["index"]["md5"][k] for k in got}, case
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, size=977).astype(np.uint8)
+    tis = np.concatenate([np.tile(unit, 20), np.zeros(5000, np.uint8),
+                          np.tile(np.array([0, 1], np.uint8), 3000),
+                          rng.integers(0, 4, 3000).astype(np.uint8),
+                          np.tile(unit, 3)])
+    tis[rng.integers(0, len(tis), size=30)] = H.WILDCARD
+    tis[12000] = H.SEPARATOR
+    gi, want = check_against_oracle(V, tis, 5)
+    assert gi.info().device_integersize == 64 and want.nllv > 1000
+    for t in ([0], [3, 2, 1, 0], [255, 255], [1] * 70):
+        check_against_oracle(V, np.array(t, np.uint8), 1)
+    # sti1 from wide tables
+    idx, _ = H.load_case("grumbach")
+    gi = V.Index.build(idx.tis, 4, idx.prefixlength)
+    assert np.array_equal(gi.make_sti1(), H.sti1_from_tables(
+        idx.suf, idx.lcp, idx.prefixlength))
+
+
+def test_search_on_a_wide_built_index(V, monkeypatch):
+    """text -> wide GPU index (deep tables included) -> every query mode"""
+    monkeypatch.setenv("VSA_FORCE_WIDE", "1")
+    idx, q = H.load_case("c1")
+    gi = V.Index.build(idx.tis, 4, 0)
+    assert gi.info().device_integersize == 64 and gi.info().deepprefix > 0
+    gq = V.Queries.from_host(q.symbols, q.start, q.length)
+    got = H.matches_as_ref(idx, V.findcompletematches(gi, gq).fetch())
+    assert np.array_equal(got, H.expected("c1", "complete"))
+    for key, kw in (("mum20", dict(mum=True)),
+                    ("mumcand20", dict(mum=True, cand=True)),
+                    ("mem20_sp0", dict(speedup=0)), ("mem20_sp2", {})):
+        if key not in M["c1"]["runs"]:
+            continue
+        got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
+                                                       **kw).fetch())
+        assert np.array_equal(got, H.expected("c1", key)), key

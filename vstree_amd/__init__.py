@@ -61,7 +61,8 @@ class IndexInfo(C.Structure):
                 ("largelcpvalues", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("prefixlength", C.c_uint32), ("numofchars", C.c_uint32),
                 ("device_integersize", C.c_uint32), ("device", C.c_int),
-                ("hasindexedqueries", C.c_int), ("hasbwt", C.c_int)]
+                ("hasindexedqueries", C.c_int), ("hasbwt", C.c_int),
+                ("deepprefix", C.c_uint32)]
 
 
 class SinkParams(C.Structure):

@@ -460,6 +460,7 @@ extern "C" int vsa_index_getinfo(const vsa_index *ix, vsa_index_info *info)
   info->device = ix->device;
   info->hasindexedqueries = ix->hasindexedqueries;
   info->hasbwt = ix->bwt != nullptr;
+  info->deepprefix = ix->esa8 != nullptr ? ix->D : 0;
   return 0;
 }
 

@@ -32,6 +32,7 @@
 #pragma once
 
 #include "vsa_internal.hpp"
+#include <type_traits>
 
 #define VSA_ISSPECIAL(c) ((c) >= (uint8_t) VSA_WILDCARD) // chardef.h:37
 
@@ -233,9 +234,9 @@ __device__ __forceinline__ uint32_t vsa_pack16(uint64_t a, uint64_t b)
 // leaves in lcplen what COMPARE / CHECKRETURN (kurtz/maxpref.c:30-65) would:
 // the position of the first mismatch, of the first special symbol of the
 // query, or querylen.  CHUNKS: pieces of 60 symbols fetched per round trip.
-template <int CHUNKS>
+template <int CHUNKS, typename IDX>
 __device__ __forceinline__ bool
-vsa_extend_packed(const DevIndex<uint32_t> &ix, uint64_t sufstart,
+vsa_extend_packed(const DevIndex<IDX> &ix, uint64_t sufstart,
                   const uint8_t *query, uint32_t querylen, uint32_t &lcplen)
 {
   const uint32_t from = lcplen;
@@ -425,9 +426,9 @@ __device__ __forceinline__ void vsa_pq_stage(const DevQueries &qs, uint64_t q0,
 }
 
 // vsa_extend_packed for a query that is in registers already
-template <int CHUNKS>
+template <int CHUNKS, typename IDX>
 __device__ __forceinline__ bool
-vsa_extend_packed_pq(const DevIndex<uint32_t> &ix, uint64_t sufstart,
+vsa_extend_packed_pq(const DevIndex<IDX> &ix, uint64_t sufstart,
                      const PackedQuery &pq, uint32_t pqoff,
                      uint32_t querylen, uint32_t &lcplen)
 {
@@ -508,12 +509,48 @@ vsa_extend_packed_pq(const DevIndex<uint32_t> &ix, uint64_t sufstart,
   return true;
 }
 
-// table accessors: esa8 carries suf and the lcp byte next to each other
+// table accessors: esa8 carries suf (32-bit tables; of a wider suf only the
+// low half, which nobody reads) and the lcp byte next to each other
 template <typename IDX, bool KEYED>
 __device__ __forceinline__ uint64_t vsa_sufstart(const DevIndex<IDX> &ix,
                                                  uint64_t i)
 {
-  return KEYED ? (ix.esa8[i] & 0xFFFFFFFFull) : (uint64_t) ix.suf[i];
+  return (KEYED && sizeof(IDX) == 4) ? (ix.esa8[i] & 0xFFFFFFFFull)
+                                     : (uint64_t) ix.suf[i];
+}
+
+// start of the suffix with index w whose esa8 entry is at hand
+template <typename IDX>
+__device__ __forceinline__ uint64_t vsa_entrystart(const DevIndex<IDX> &ix,
+                                                   uint64_t entry, uint64_t w)
+{
+  if constexpr (sizeof(IDX) == 4)
+  {
+    return entry & 0xFFFFFFFFull;
+  } else
+  {
+    return (uint64_t) ix.suf[w];
+  }
+}
+
+// word 0 of a deep bucket's slot (and the entries of bck2): 32-bit tables
+// left | mid << 32; wide tables left (40 bits) | number of suffixes << 40 --
+// an index whose deep buckets do not fit 24 bits gets no deep tables
+#define VSA_WIDE_LEFTBITS 40
+template <typename IDX>
+__device__ __forceinline__ void vsa_slotbounds(uint64_t b, uint64_t &left,
+                                               uint32_t &cnt)
+{
+  if constexpr (sizeof(IDX) == 4)
+  {
+    const uint32_t dl = (uint32_t) b, dm = (uint32_t) (b >> 32);
+    left = dl;
+    cnt = (dm > dl) ? dm - dl : 0;
+  } else
+  {
+    left = b & ((1ull << VSA_WIDE_LEFTBITS) - 1);
+    cnt = (uint32_t) (b >> VSA_WIDE_LEFTBITS);
+  }
 }
 
 template <typename IDX, bool KEYED>
@@ -737,7 +774,7 @@ vsa_locate_reference(const DevIndex<IDX> &ix, const uint8_t *query,
   return true;
 }
 
-// ---- deep locate (DNA, 32-bit tables) -------------------------------------
+// ---- deep locate (DNA) ------------------------------------------------------
 
 // eight symbols (one byte each, 0..3) -> 16 bits, first symbol most
 // significant, so that integers compare like the strings they pack
@@ -795,9 +832,10 @@ struct DeepHit
   bool notleftmax;  // see vsa_locate_deep, qleft
 };
 
-template <int AHEAD = 1, bool DEFER = false, bool PQ = false>
+template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
+          typename IDX = uint32_t>
 __device__ __forceinline__ int
-vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
+vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
                 uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
                 uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
@@ -821,7 +859,9 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   int state = VSA_LOC_NONE;
-  uint32_t dl = 0, cnt = 0, qkey = 0, limit = 0;
+  // first suffix of the deep bucket: a register pair only for wide tables
+  typename std::conditional<sizeof(IDX) == 4, uint32_t, uint64_t>::type dl = 0;
+  uint32_t cnt = 0, qkey = 0, limit = 0;
   uint64_t first = 0, second = 0, third = 0; // esa8[dl..] from the fused table
 
   if (active)
@@ -901,9 +941,9 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
         b = vsa_ld_entry(reinterpret_cast<const uint64_t *>(ix.bck2) + code,
                          nt);
       }
-      dl = (uint32_t) b;
-      const uint32_t dm = (uint32_t) (b >> 32);
-      cnt = (dm > dl) ? dm - dl : 0;
+      uint64_t bleft;
+      vsa_slotbounds<IDX>(b, bleft, cnt);
+      dl = (decltype(dl)) bleft;
       state = (cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
     }
   }
@@ -1115,18 +1155,18 @@ vsa_locate_deep(const DevIndex<uint32_t> &ix, bool active,
     // round trip when the caller expects long matches); lanes whose
     // comparison met a special symbol of the text repeat it on the bytes
     bool done = false;
+    const uint64_t sstart = vsa_entrystart(ix, esucc, (uint64_t) dl + lo);
     if (ix.tis2 != nullptr)
     {
       done = PQ ? vsa_extend_packed_pq<(AHEAD > 1 ? 2 : 1)>(
-                      ix, esucc & 0xFFFFFFFFull, *pq, pqoff, querylen, lcplen)
+                      ix, sstart, *pq, pqoff, querylen, lcplen)
                 : vsa_extend_packed<(AHEAD > 1 ? 2 : 1)>(
-                      ix, esucc & 0xFFFFFFFFull, query, querylen, lcplen);
+                      ix, sstart, query, querylen, lcplen);
     }
     if (!done)
     {
       lcplen = maxlcp;
-      (void) vsa_compare32<uint32_t, AHEAD>(ix, esucc & 0xFFFFFFFFull, query,
-                                            querylen, lcplen);
+      (void) vsa_compare32<IDX, AHEAD>(ix, sstart, query, querylen, lcplen);
     }
     maxlcp = lcplen;
   }

@@ -408,7 +408,6 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   tall.start();
   VSA_HIP(hipMemsetAsync(count.as<uint64_t>() + qlimit, 0, 8, stream));
   tsearch.start();
-  if constexpr (sizeof(IDX) == 4)
   {
     const bool staged = ix.esa8 != nullptr && qs.dense != 0 &&
                         qs.uniformlen <= 128 && (qs.uniformlen & 3u) == 0 &&
@@ -429,10 +428,6 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
           <<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
               ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
     }
-  } else
-  {
-    k_complete_search<IDX, false><<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
-        ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
   }
   tsearch.stop();
   VSA_HIP(hipGetLastError());
@@ -943,11 +938,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   }
   const uint32_t nshards = VSA_CURSOR_SHARDS;
   const int qblock = (int) ((index->tune >> 8) & 0xFFF); // experiment switch
-  bool deepok = false;
-  if constexpr (sizeof(IDX) == 4)
-  {
-    deepok = ix.esa8 != nullptr && searchlength >= ix.D;
-  }
+  const bool deepok = ix.esa8 != nullptr && searchlength >= ix.D;
   tall.start();
   // MUM modes over batches of equal-length queries: anchor pass + work list
   DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist, wfirste,
@@ -1005,7 +996,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       tfirst.start();
       if (deepok)
       {
-        if constexpr (sizeof(IDX) == 4)
         {
           // reads of one length m (a multiple of 4, <= 128), back to back:
           // staged through LDS and packed (VSA_TUNE bit 7: without)
@@ -1038,11 +1028,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       tfirst.stop();
     } else if (deepok)
     {
-      if constexpr (sizeof(IDX) == 4)
-      {
-        k_mum_anchor<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-            ix, qs, perquery, searchlength, wcount.as<uint32_t>());
-      }
+      k_mum_anchor<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          ix, qs, perquery, searchlength, wcount.as<uint32_t>());
     } else
     {
       k_mum_anchor<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
@@ -1093,13 +1080,10 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       {
         if (deepok)
         {
-          if constexpr (sizeof(IDX) == 4)
-          {
-            k_mum_plan<IDX, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-                ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
-                firstpass ? wfirste.as<uint32_t>() : nullptr,
-                wcount.as<uint32_t>(), wplan.as<PlanRanges>());
-          }
+          k_mum_plan<IDX, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+              ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+              firstpass ? wfirste.as<uint32_t>() : nullptr,
+              wcount.as<uint32_t>(), wplan.as<PlanRanges>());
         } else
         {
           k_mum_plan<IDX, false><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
@@ -1115,10 +1099,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     // plans itself (k_query_search_planned) -- no scan over the queries, no
     // work list, no read-back of its length (a workgroup size in VSA_TUNE bits
     // 8-19, e.g. VSA_TUNE=256, selects the list form)
-    if constexpr (sizeof(IDX) == 4)
-    {
-      fromplan = planned && domum && deepok && qblock == 0;
-    }
+    fromplan = planned && domum && deepok && qblock == 0;
     if (fromplan)
     {
       tanchor.stop();
@@ -1331,12 +1312,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   } while (0)
     // deep locate needs the deep prefix to fit into every search
     bool deep = nwork == 0; // nothing left to search: no launch at all
-    if constexpr (sizeof(IDX) == 4)
     {
       deep = deep || deepok;
       if (fromplan)
       {
-        k_query_search_planned<256>
+        k_query_search_planned<IDX, 256>
             <<<(unsigned int) nplanblocks, 256, 0, stream>>>(
                 ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
                 wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
@@ -1345,8 +1325,15 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
                 blocksum.as<unsigned long long>());
       } else if (deep && nwork > 0)
       {
-        if (domum && defer)
+        bool deferred = false;
+        if constexpr (sizeof(IDX) == 4) // (the experiment has 32-bit records)
         {
+          deferred = domum && defer;
+        }
+        if (deferred)
+        {
+          if constexpr (sizeof(IDX) == 4)
+          {
 #define VSA_LAUNCH_DEFER(BLK)                                                  \
   k_query_search<IDX, true, true, BLK, true>                                  \
       <<<(unsigned int) nblocksq, BLK, k2lds, stream>>>(                      \
@@ -1376,6 +1363,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
               defcursor.as<unsigned long long>(), rawout.as<vsa_match>(),
               rawkeys.as<uint64_t>(), shardcap,
               cursor.as<unsigned long long>(), packbits, valbits);
+          }
         } else if (domum)
         {
           VSA_LAUNCH_QUERY(true, true);
@@ -1751,8 +1739,9 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
 // the keyed search array (see DevIndex::esa8)
 // ---------------------------------------------------------------------------
 
+template <typename IDX>
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
+k_make_esa8(const uint8_t *__restrict__ tis, const IDX *__restrict__ suf,
             const uint8_t *__restrict__ lcp, uint64_t count, uint32_t D,
             uint64_t *__restrict__ esa8)
 {
@@ -1761,8 +1750,8 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
   {
     return;
   }
-  const uint32_t s = suf[j];
-  const uint8_t *t = tis + (uint64_t) s + D; // padded with 0xFF behind n
+  const uint64_t s = suf[j];
+  const uint8_t *t = tis + s + D; // padded with 0xFF behind n
   uint64_t key = 0, flag = 0;
 #pragma unroll
   for (uint32_t k = 0; k < VSA_KEYSYMS; k++)
@@ -1778,7 +1767,8 @@ k_make_esa8(const uint8_t *__restrict__ tis, const uint32_t *__restrict__ suf,
   const uint8_t l = tis[(int64_t) s - 1];
   const uint64_t left = VSA_ISSPECIAL(l) ? VSA_LEFTSPECIAL
                                          : ((uint64_t) (l & 3) << VSA_LEFTSHIFT);
-  esa8[j] = (uint64_t) s | ((uint64_t) lcp[j] << 32) |
+  // (of a wide suf only the low half: vsa_entrystart reads suf itself then)
+  esa8[j] = (s & 0xFFFFFFFFull) | ((uint64_t) lcp[j] << 32) |
             (key << VSA_KEYSHIFT) | flag | left;
 }
 
@@ -1832,17 +1822,30 @@ k_pack_text(const uint8_t *__restrict__ tis, uint64_t n, uint64_t nblocks,
 // slot[code] = (bck2 pair, the first W-1 entries of the bucket), W = 2 or 4
 // words; entries the bucket does not have are 0 (they stand for the entry
 // behind the bucket, whose lcp byte is below D anyway)
-template <int W>
+// Wide tables: word 0 in the form of vsa_slotbounds (left | count << 40);
+// *toobig is set when a bucket's count does not fit.
+template <int W, typename IDX>
 __global__ void __launch_bounds__(VSA_BLOCK)
-k_make_slots(const uint32_t *__restrict__ bck2,
-             const uint64_t *__restrict__ esa8, uint64_t ncodes,
-             uint64_t *__restrict__ slot)
+k_make_slots(const IDX *__restrict__ bck2, const uint64_t *__restrict__ esa8,
+             uint64_t ncodes, uint64_t *__restrict__ slot,
+             unsigned int *__restrict__ toobig)
 {
   for (uint64_t c = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
        c < ncodes; c += (uint64_t) gridDim.x * VSA_BLOCK)
   {
-    const uint32_t left = bck2[2 * c], mid = bck2[2 * c + 1];
-    slot[W * c] = (uint64_t) left | ((uint64_t) mid << 32);
+    const IDX left = bck2[2 * c], mid = bck2[2 * c + 1];
+    if constexpr (sizeof(IDX) == 4)
+    {
+      slot[W * c] = (uint64_t) left | ((uint64_t) mid << 32);
+    } else
+    {
+      const uint64_t cnt = mid > left ? mid - left : 0;
+      if (cnt >> (64 - VSA_WIDE_LEFTBITS) != 0)
+      {
+        *toobig = 1;
+      }
+      slot[W * c] = left | (cnt << VSA_WIDE_LEFTBITS);
+    }
 #pragma unroll
     for (int k = 0; k + 1 < W; k++)
     {
@@ -1875,7 +1878,9 @@ int vsa_index_make_esa8(vsa_index *ix)
     (void) hipFree(ix->spec64);
     ix->tis2 = ix->spec64 = nullptr;
   }
-  if (ix->numofchars != 4 || ix->isize != 4 || ix->bck == nullptr ||
+  const bool wide = ix->isize != 4;
+  if (ix->numofchars != 4 || ix->bck == nullptr ||
+      (wide && ((ix->n + 1) >> VSA_WIDE_LEFTBITS) != 0) ||
       (off != nullptr && strcmp(off, "1") == 0))
   {
     return 0;
@@ -1906,18 +1911,29 @@ int vsa_index_make_esa8(vsa_index *ix)
   const char *tune = getenv("VSA_TUNE");
   ix->tune = tune != nullptr ? (uint32_t) atoi(tune) : 0;
   const uint64_t count = ix->n + 1, ncodes = 1ull << (2 * D);
-  VSA_HIP(vsa_hip_malloc((void **) &ix->bck2, 2 * ncodes * 4 + 16));
+  VSA_HIP(vsa_hip_malloc((void **) &ix->bck2, 2 * ncodes * ix->isize + 16));
   VSA_HIP(vsa_hip_malloc((void **) &ix->esa8, count * 8 + 64));
-  ix->device_bytes += count * 8 + 2 * ncodes * 4;
-  if (vsa_build_bucket_table(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
-                             (const uint32_t *) ix->suf, D, 4, ix->bck2,
-                             ix->stream))
+  ix->device_bytes += count * 8 + 2 * ncodes * ix->isize;
+  if (wide ? vsa_build_bucket_table(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
+                                    (const uint64_t *) ix->suf, D, 4,
+                                    (uint64_t *) ix->bck2, ix->stream)
+           : vsa_build_bucket_table(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
+                                    (const uint32_t *) ix->suf, D, 4,
+                                    ix->bck2, ix->stream))
   {
     return -100;
   }
-  k_make_esa8<<<gridfor(count), VSA_BLOCK, 0, ix->stream>>>(
-      ix->tis_alloc + VSA_TIS_FRONTPAD, (const uint32_t *) ix->suf, ix->lcp,
-      count, D, ix->esa8);
+  if (wide)
+  {
+    k_make_esa8<uint64_t><<<gridfor(count), VSA_BLOCK, 0, ix->stream>>>(
+        ix->tis_alloc + VSA_TIS_FRONTPAD, (const uint64_t *) ix->suf, ix->lcp,
+        count, D, ix->esa8);
+  } else
+  {
+    k_make_esa8<uint32_t><<<gridfor(count), VSA_BLOCK, 0, ix->stream>>>(
+        ix->tis_alloc + VSA_TIS_FRONTPAD, (const uint32_t *) ix->suf, ix->lcp,
+        count, D, ix->esa8);
+  }
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(ix->stream));
   // the 2-bit text for long comparisons (VSA_PACKED_TEXT=0: without)
@@ -1962,6 +1978,13 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     slotbytes = 16;
   }
+  if (wide && slotbytes == 0)
+  {
+    slotbytes = 16; // wide tables have the fused form only
+  }
+  unsigned int *dtoobig = nullptr, htoobig = 0;
+  VSA_HIP(vsa_hip_malloc((void **) &dtoobig, 4));
+  VSA_HIP(hipMemsetAsync(dtoobig, 0, 4, ix->stream));
   for (; slotbytes >= 16; slotbytes -= 16)
   {
     const uint32_t words = (uint32_t) slotbytes / 8;
@@ -1974,22 +1997,64 @@ int vsa_index_make_esa8(vsa_index *ix)
     }
     const unsigned int grid = (unsigned int) std::min<uint64_t>(
         (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20);
-    if (words == 4)
+    if (wide)
     {
-      k_make_slots<4><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-          ix->bck2, ix->esa8, ncodes, ix->slot16);
+      const uint64_t *pairs = (const uint64_t *) ix->bck2;
+      if (words == 4)
+      {
+        k_make_slots<4, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+            pairs, ix->esa8, ncodes, ix->slot16, dtoobig);
+      } else
+      {
+        k_make_slots<2, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+            pairs, ix->esa8, ncodes, ix->slot16, dtoobig);
+      }
+    } else if (words == 4)
+    {
+      k_make_slots<4, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
     } else
     {
-      k_make_slots<2><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-          ix->bck2, ix->esa8, ncodes, ix->slot16);
+      k_make_slots<2, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
     }
     VSA_HIP(hipGetLastError());
+    VSA_HIP(hipMemcpyAsync(&htoobig, dtoobig, 4, hipMemcpyDeviceToHost,
+                           ix->stream));
     VSA_HIP(hipStreamSynchronize(ix->stream));
     (void) hipFree(ix->bck2);
     ix->bck2 = nullptr;
     ix->slotwords = words;
-    ix->device_bytes += (uint64_t) words * ncodes * 8 - 2 * ncodes * 4;
+    ix->device_bytes += (uint64_t) words * ncodes * 8 - 2 * ncodes * ix->isize;
     break;
+  }
+  (void) hipFree(dtoobig);
+  if (wide && (ix->slot16 == nullptr || htoobig != 0))
+  {
+    // no room for the fused table, or a deep bucket with 2^24 suffixes or
+    // more: this index is searched the reference's way
+    const uint64_t nblocks = (ix->n >> 6) + 1, nwaves = (nblocks + 63) / 64;
+    ix->device_bytes -= count * 8;
+    if (ix->slot16 != nullptr)
+    {
+      ix->device_bytes -= (uint64_t) ix->slotwords * ncodes * 8;
+    } else
+    {
+      ix->device_bytes -= 2 * ncodes * ix->isize;
+    }
+    if (ix->tis2 != nullptr)
+    {
+      ix->device_bytes -= nblocks * 16 + nwaves * 8;
+    }
+    (void) hipFree(ix->esa8);
+    (void) hipFree(ix->bck2);
+    (void) hipFree(ix->slot16);
+    (void) hipFree(ix->tis2);
+    (void) hipFree(ix->spec64);
+    ix->esa8 = ix->slot16 = nullptr;
+    ix->bck2 = nullptr;
+    ix->tis2 = ix->spec64 = nullptr;
+    ix->D = 0;
   }
   return 0;
 }
