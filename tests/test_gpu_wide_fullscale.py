@@ -1,0 +1,127 @@
+"""An index beyond 2^32 positions (the reference's 64-bit Uint build,
+include/types.h:41-61): 4.4 Gbp of synthetic DNA, tables built on the GPU
+with 64-bit suf/bck/llv, deep-locate tables in their wide form, searched by
+2 M x 100 bp reads.  Checked like the 3 Gbp index of test_gpu_fullscale.py:
+  * structure of the tables (suf a permutation, adjacent suffixes in order
+    and lcp exact on a sample, bck brackets the q-grams);
+  * the CPU oracle on the SAME tables for a sample of the reads: complete /
+    MEM / MUM candidates / MUM lists identical, in order;
+  * planted answers: every unmodified read is found where it was cut, and
+    reads cut from positions >= 2^32 are among them;
+  * the reference's MUM filter (CPU) over all GPU candidates == the GPU's
+    MUM list; sampled MUMs are maximal exact matches in the text.
+VSA_WIDE_BP / VSA_WIDE_QUERIES change the size; VSA_WIDE_BP=0 skips the
+module (it needs ~230 GB of HBM while the derived tables are made)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import test_gpu_fullscale as F
+
+pytestmark = pytest.mark.gpu
+
+N = int(float(os.environ.get("VSA_WIDE_BP", "4.4e9")))
+NQ = int(float(os.environ.get("VSA_WIDE_QUERIES", "2e6")))
+M, L = 100, 20
+
+
+@pytest.fixture(scope="module")
+def world(V):
+    if N == 0:
+        pytest.skip("VSA_WIDE_BP=0")
+    V.lib.vsa_device_trim(0)
+    dg = V.device_malloc(N + 64)
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, N, dg, 0))
+    pos, sub, step = V.synth_query_plan(N, NQ, M)
+    dq = V.device_malloc(NQ * M + 64)
+    V._check(V.lib.vsa_synth_queries_device(dg, N, pos.ctypes.data,
+                                            sub.ctypes.data, step.ctypes.data,
+                                            NQ, M, dq, 0))
+    queries = V.Queries.from_device(dq, NQ, M)
+    V.device_free(dq)
+    index = V.Index.build_device(dg, N, 4, 0)
+    V.device_free(dg)
+    t = index.download()
+    info = index.info()
+    host = H.Index(N, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
+                   t["llv"], t["bck"], t["bwt"], None)
+    yield dict(index=index, queries=queries, host=host, pos=pos, sub=sub,
+               step=step, info=info)
+    index.close()
+    V.lib.vsa_device_trim(0)
+
+
+def test_the_tables_are_wide_and_have_the_deep_form(world):
+    info = world["info"]
+    assert info.totallength == N
+    if N + 1 >= 1 << 32:
+        assert info.device_integersize == 64
+    assert info.deepprefix == 16
+    assert info.prefixlength == H.recommended_prefixlength(4, N)
+    assert world["host"].suf.dtype == (np.uint64 if N + 1 >= 1 << 32
+                                       else np.uint32)
+
+
+def test_index_structure(world):
+    F.test_index_structure(world)
+    if N + 1 >= 1 << 32:
+        assert int(world["host"].suf.max()) == N     # beyond 32 bits
+
+
+def test_sample_parity_with_cpu_oracle_on_the_wide_index(V, world):
+    # reads from all over the text, the upper end included
+    order = np.argsort(world["pos"], kind="stable")
+    sel = np.sort(np.concatenate([order[-700:], order[::max(1, NQ // 1300)]
+                                  [:1300]]))
+    sel = np.unique(sel)
+    hq = F.host_queries(world, sel)
+    gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
+    ix, host = world["index"], world["host"]
+    got = V.findcompletematches(ix, gq).fetch()
+    assert np.array_equal(got, H.oracle_complete(host, hq))
+    if N + 1 >= 1 << 32:
+        assert (got["dbstart"] >= 1 << 32).sum() >= 300
+    for kw in ({}, dict(mum=True, cand=True), dict(mum=True)):
+        assert np.array_equal(
+            V.findquerymatches(ix, gq, L, speedup=0, **kw).fetch(),
+            H.oracle_querymatches(host, hq, L, speedup=0, **kw)), kw
+
+
+def test_planted_answers_and_global_mum_filter(V, world):
+    ix, q = world["index"], world["queries"]
+    m = V.findcompletematches(ix, q).fetch()
+    exact = world["sub"] == 0xFFFFFFFF
+    assert (m["length"] == M).all()
+    planted = np.zeros(NQ, bool)
+    hit = m["dbstart"] == world["pos"][m["queryseq"]]
+    planted[m["queryseq"][hit]] = True
+    assert planted[exact].all()
+    if N + 1 >= 1 << 32:
+        high = world["pos"] >= 1 << 32
+        assert (exact & high).sum() > NQ // 200 and planted[exact & high].all()
+    assert (np.diff(m["queryseq"].astype(np.int64)) >= 0).all()
+    tis = world["host"].tis
+    rng = np.random.default_rng(2)
+    cand = V.findquerymatches(ix, q, L, mum=True, cand=True).fetch()
+    assert (np.diff((cand["queryseq"] * np.uint64(M)
+                     + cand["querystart"]).astype(np.int64)) > 0).all()
+    mums = V.findquerymatches(ix, q, L, mum=True).fetch()
+    import ctypes as C
+    out = H.OrcMatches()
+    lib = H.oracle_lib()
+    lib.orc_matches_init(C.byref(out))
+    c2 = np.ascontiguousarray(cand.copy())
+    lib.orc_mumuniqueinquery(c2.ctypes.data, len(c2), C.byref(out))
+    assert np.array_equal(mums, H._take(out))
+    assert (np.diff(mums["dbstart"].astype(np.int64)) >= 0).all()
+    if N + 1 >= 1 << 32:
+        assert (mums["dbstart"] >= 1 << 32).sum() > len(mums) // 200
+    for k in rng.integers(0, len(mums), size=2000):
+        ln, s, qi, qo = (int(mums[f][k]) for f in
+                         ("length", "dbstart", "queryseq", "querystart"))
+        hq = F.host_queries(world, [qi]).symbols
+        assert np.array_equal(tis[s:s + ln], hq[qo:qo + ln])
+        assert qo + ln == M or s + ln == N or tis[s + ln] != hq[qo + ln]
+        assert qo == 0 or s == 0 or tis[s - 1] != hq[qo - 1]

@@ -664,7 +664,7 @@ extern "C" int vsa_queries_from_host(const uint8_t *symbols,
 __global__ void k_uniform_starts(uint64_t *start, uint64_t *length,
                                  uint64_t nq, uint64_t m)
 {
-  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = vsa_bid() * blockDim.x + threadIdx.x;
   if (i < nq)
   {
     start[i] = i * m;
@@ -709,7 +709,7 @@ extern "C" int vsa_queries_from_device(const void *device_symbols,
   VSA_HIPQ(q, queries, hipMemset(q->symbols + q->nsymbols, 0xFF, VSA_QUERY_BACKPAD));
   if (nq > 0)
   {
-    k_uniform_starts<<<(unsigned int) ((nq + 255) / 256), 256>>>(
+    k_uniform_starts<<<vsa_grid((nq + 255) / 256), 256>>>(
         q->start, q->length, nq, m);
     VSA_HIPQ(q, queries, hipGetLastError());
     VSA_HIPQ(q, queries, hipDeviceSynchronize());
@@ -726,7 +726,7 @@ k_reverse_complement(const uint8_t *__restrict__ in,
                      uint8_t *__restrict__ out, uint32_t *__restrict__ bad)
 {
   // one wavefront per sequence, lanes stride over its symbols
-  const uint64_t q = ((uint64_t) blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint64_t q = (vsa_bid() * 256 + threadIdx.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   if (q >= nq)
   {
@@ -794,7 +794,7 @@ extern "C" int vsa_queries_reverse_complement(const vsa_queries *q,
                     hipMemcpyDeviceToDevice));
   if (r->nq > 0)
   {
-    k_reverse_complement<<<(unsigned int) ((r->nq * 64 + 255) / 256), 256>>>(
+    k_reverse_complement<<<vsa_grid((r->nq * 64 + 255) / 256), 256>>>(
         q->symbols, q->start, q->length, r->nq, r->symbols, dbad);
     VSA_HIPQ(r, rcqueries, hipGetLastError());
   }
@@ -940,8 +940,8 @@ __global__ void __launch_bounds__(256)
 k_stream_read(const uint4 *__restrict__ p, uint64_t n16,
               unsigned long long *sink)
 {
-  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+  uint64_t i = vsa_bid() * blockDim.x + threadIdx.x;
+  const uint64_t stride = vsa_nblocks() * blockDim.x;
   uint32_t acc = 0;
   for (; i < n16; i += stride)
   {
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(256)
 k_random_read(const uint64_t *__restrict__ buf, uint64_t nwords,
               uint64_t perthread, unsigned long long *__restrict__ sink)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+  const uint64_t t = vsa_bid() * 256 + threadIdx.x;
   uint64_t x = t * 0x9E3779B97F4A7C15ull + 1, acc = 0;
   for (uint64_t i = 0; i < perthread; i += INFLIGHT)
   {

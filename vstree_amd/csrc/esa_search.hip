@@ -216,9 +216,14 @@ k_shard_summary(const unsigned long long *__restrict__ cursors,
   }
 }
 
-inline unsigned int gridfor(uint64_t items)
+inline uint64_t blocksfor(uint64_t items)
 {
-  return (unsigned int) ((items + VSA_BLOCK - 1) / VSA_BLOCK);
+  return (items + VSA_BLOCK - 1) / VSA_BLOCK;
+}
+
+inline dim3 gridfor(uint64_t items)
+{
+  return vsa_grid(blocksfor(items));
 }
 
 // out[] = the records of in[] with keep != 0, in order; *nkept (device) = count
@@ -300,7 +305,7 @@ unsigned int bitsfor(uint64_t maxvalue)
 __global__ void __launch_bounds__(VSA_BLOCK)
 k_iota_u32(uint32_t *__restrict__ out, uint64_t n)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
   if (t < n)
   {
     out[t] = (uint32_t) t;
@@ -312,7 +317,7 @@ k_gather_matches(const vsa_match *__restrict__ in,
                  const uint32_t *__restrict__ order, uint64_t n,
                  vsa_match *__restrict__ out)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
   if (t < n)
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(in + order[t]);
@@ -506,7 +511,7 @@ k_mum_compositekeys(const vsa_match *__restrict__ cand, uint64_t n,
                     unsigned int lenbits, uint64_t *__restrict__ key,
                     uint32_t *__restrict__ idx)
 {
-  const uint64_t i = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t i = vsa_bid() * VSA_BLOCK + threadIdx.x;
   if (i < n)
   {
     const uint64_t lenmask = (1ull << lenbits) - 1;
@@ -689,12 +694,12 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
                                     (uint32_t) 0, (size_t) ncand,
                                     rocprim::plus<uint32_t>(), stream));
     DevBuf blocksum;
-    const size_t nblocks = gridfor(ncand);
-    if (blocksum.alloc(nblocks * 8))
+    const size_t nblocks = blocksfor(ncand);
+    if (blocksum.alloc(vsa_grid_blocks(nblocks) * 8))
     {
       return -100;
     }
-    k_mum_writekept<<<nblocks, VSA_BLOCK, 0, stream>>>(
+    k_mum_writekept<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
         cand.as<vsa_match>(), i2.as<uint32_t>(), keep.as<uint8_t>(),
         slots.as<uint32_t>(), ncand, mums.as<vsa_match>(),
         dcount.as<uint64_t>(), blocksum.as<unsigned long long>());
@@ -763,11 +768,12 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     return 0;
   }
   DevBuf k2, v2, dbright, keep, slots, temp, dcount, blocksum;
-  const size_t nblocks = gridfor(ncand);
+  const size_t nblocks = blocksfor(ncand);
   if (k2.alloc(ncand * 8) || v2.alloc(ncand * sizeof(VAL)) ||
       dbright.alloc(ncand * 8) ||
       keep.alloc(ncand) || slots.alloc(ncand * 4) || dcount.alloc(24) ||
-      blocksum.alloc(nblocks * 8) || mums.alloc(ncand * sizeof(vsa_match)))
+      blocksum.alloc(vsa_grid_blocks(nblocks) * 8) ||
+      mums.alloc(ncand * sizeof(vsa_match)))
   {
     return -100;
   }
@@ -808,12 +814,12 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
                                     rocprim::maximum<uint64_t>(), stream));
     if (byruns)
     {
-      k_mum_keyflags_runs<<<nblocks, VSA_BLOCK, 0, stream>>>(
+      k_mum_keyflags_runs<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
           k2.as<uint64_t>(), dbright.as<uint64_t>(), ncand, lenbits,
           keep.as<uint8_t>(), dcount.as<unsigned int>() + 4);
     } else
     {
-      k_mum_keyflags<<<nblocks, VSA_BLOCK, 0, stream>>>(
+      k_mum_keyflags<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
           k2.as<uint64_t>(), dbright.as<uint64_t>(), ncand, lenbits,
           keep.as<uint8_t>());
     }
@@ -831,7 +837,7 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     VSA_HIP(rocprim::exclusive_scan(temp.p, tb, keepit, slots.as<uint32_t>(),
                                     (uint32_t) 0, (size_t) ncand,
                                     rocprim::plus<uint32_t>(), stream));
-    k_mum_writepacked<VAL><<<nblocks, VSA_BLOCK, 0, stream>>>(
+    k_mum_writepacked<VAL><<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
         k2.as<uint64_t>(), v2.as<VAL>(), keep.as<uint8_t>(),
         slots.as<uint32_t>(), ncand, lenbits, valbits, seqoffset,
         mums.as<vsa_match>(), dcount.as<uint64_t>(),
@@ -1163,7 +1169,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     // the work-items of the planned search: summed per workgroup by the
     // kernel, reduced behind it, read back with the shard summary
-    if (blocksum.alloc((nplanblocks + 1) * 8) || rsum.alloc(8))
+    if (blocksum.alloc((vsa_grid_blocks(nplanblocks) + 1) * 8) ||
+        rsum.alloc(8))
     {
       return -100;
     }
@@ -1289,7 +1296,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     tsearch.start();
 #define VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, BLK)                              \
   k_query_search<IDX, MUMFLAG, KEYFLAG, BLK>                                  \
-      <<<(unsigned int) ((nwork + BLK - 1) / BLK), BLK, k2lds, stream>>>(     \
+      <<<vsa_grid((nwork + BLK - 1) / BLK), BLK, k2lds, stream>>>(            \
           ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
@@ -1317,7 +1324,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       if (fromplan)
       {
         k_query_search_planned<IDX, 256>
-            <<<(unsigned int) nplanblocks, 256, 0, stream>>>(
+            <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
                 ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
                 wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
                 rawkeys.as<uint64_t>(), shardcap, nshards - 1,
@@ -1336,7 +1343,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           {
 #define VSA_LAUNCH_DEFER(BLK)                                                  \
   k_query_search<IDX, true, true, BLK, true>                                  \
-      <<<(unsigned int) nblocksq, BLK, k2lds, stream>>>(                      \
+      <<<vsa_grid(nblocksq), BLK, k2lds, stream>>>(                           \
           ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits,    \
@@ -1745,7 +1752,7 @@ k_make_esa8(const uint8_t *__restrict__ tis, const IDX *__restrict__ suf,
             const uint8_t *__restrict__ lcp, uint64_t count, uint32_t D,
             uint64_t *__restrict__ esa8)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VSA_BLOCK + threadIdx.x;
   if (j >= count)
   {
     return;
@@ -1780,7 +1787,7 @@ k_pack_text(const uint8_t *__restrict__ tis, uint64_t n, uint64_t nblocks,
             uint8_t *__restrict__ tis2, uint8_t *__restrict__ spec64,
             unsigned long long *__restrict__ firstspecial)
 {
-  const uint64_t b = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t b = vsa_bid() * VSA_BLOCK + threadIdx.x;
   bool special = false;
   if (b < nblocks)
   {
@@ -1830,8 +1837,8 @@ k_make_slots(const IDX *__restrict__ bck2, const uint64_t *__restrict__ esa8,
              uint64_t ncodes, uint64_t *__restrict__ slot,
              unsigned int *__restrict__ toobig)
 {
-  for (uint64_t c = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
-       c < ncodes; c += (uint64_t) gridDim.x * VSA_BLOCK)
+  for (uint64_t c = vsa_bid() * VSA_BLOCK + threadIdx.x;
+       c < ncodes; c += vsa_nblocks() * VSA_BLOCK)
   {
     const IDX left = bck2[2 * c], mid = bck2[2 * c + 1];
     if constexpr (sizeof(IDX) == 4)
@@ -1953,7 +1960,7 @@ int vsa_index_make_esa8(vsa_index *ix)
     VSA_HIP(hipMemsetAsync(ix->spec64 + nwaves * 8, 0xFF, 64, ix->stream));
     VSA_HIP(hipMemcpyAsync(dfirst, &hfirst, 8, hipMemcpyHostToDevice,
                            ix->stream));
-    k_pack_text<<<(unsigned int) (nwaves * 64 / VSA_BLOCK + 1), VSA_BLOCK, 0,
+    k_pack_text<<<vsa_grid(nwaves * 64 / VSA_BLOCK + 1), VSA_BLOCK, 0,
                   ix->stream>>>(ix->tis_alloc + VSA_TIS_FRONTPAD, ix->n,
                                 nblocks, ix->tis2, ix->spec64, dfirst);
     VSA_HIP(hipGetLastError());
@@ -2272,7 +2279,11 @@ k_partition_count(const PartInput in, uint64_t n,
 {
   __shared__ unsigned int hist[VSA_PART_MAX];
   __shared__ unsigned long long top[VSA_PART_MAX];
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (vsa_bid() >= nblocks) // surplus block of a folded grid
+  {
+    return;
+  }
+  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
   for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
   {
     hist[p] = 0;
@@ -2291,8 +2302,8 @@ k_partition_count(const PartInput in, uint64_t n,
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
   {
-    blockhist[(uint64_t) p * nblocks + blockIdx.x] = hist[p];
-    blocktop[(uint64_t) p * nblocks + blockIdx.x] = top[p];
+    blockhist[(uint64_t) p * nblocks + vsa_bid()] = hist[p];
+    blocktop[(uint64_t) p * nblocks + vsa_bid()] = top[p];
   }
 }
 
@@ -2305,7 +2316,7 @@ k_partition_summary(const uint64_t *__restrict__ offsets,
                     unsigned long long *__restrict__ parttop)
 {
   __shared__ unsigned long long red[VSA_BLOCK];
-  const uint32_t p = blockIdx.x;
+  const uint32_t p = vsa_bid();
   unsigned long long best = 0;
   for (uint64_t b = threadIdx.x; b < nblocks; b += VSA_BLOCK)
   {
@@ -2340,7 +2351,11 @@ k_partition_place(const PartInput in, uint64_t n,
                   void *__restrict__ out)
 {
   __shared__ unsigned int taken[VSA_PART_MAX];
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  if (vsa_bid() >= nblocks) // surplus block of a folded grid
+  {
+    return;
+  }
+  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
   for (uint32_t p = threadIdx.x; p < nparts; p += VSA_BLOCK)
   {
     taken[p] = 0;
@@ -2352,7 +2367,7 @@ k_partition_place(const PartInput in, uint64_t n,
     const uint64_t k = in.key[t], v = in.val[t];
     const uint32_t p =
         (uint32_t) (((k >> in.packbits) * nparts) / (totallength + 1));
-    const uint64_t slot = offsets[(uint64_t) p * nblocks + blockIdx.x] +
+    const uint64_t slot = offsets[(uint64_t) p * nblocks + vsa_bid()] +
                           atomicAdd(&taken[p], 1u);
     uint4 row;
     row.x = (uint32_t) k;
@@ -2366,7 +2381,7 @@ k_partition_place(const PartInput in, uint64_t n,
     const uint4 lo = src[0], hi = src[1];
     const uint64_t dbstart = ((uint64_t) lo.w << 32) | lo.z;
     const uint32_t p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
-    const uint64_t slot = offsets[(uint64_t) p * nblocks + blockIdx.x] +
+    const uint64_t slot = offsets[(uint64_t) p * nblocks + vsa_bid()] +
                           atomicAdd(&taken[p], 1u);
     uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<vsa_match *>(out) +
                                            slot);
@@ -2406,7 +2421,7 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   }
   hipStream_t stream = nullptr;
   vsa_dev_set_stream(stream);
-  const uint64_t nblocks = gridfor(n), cells = (uint64_t) nparts * nblocks;
+  const uint64_t nblocks = blocksfor(n), cells = (uint64_t) nparts * nblocks;
   DevBuf hist, top, offsets, summary, temp;
   uint64_t host[2 * VSA_PART_MAX + 1];
   size_t tb = 0;
@@ -2422,7 +2437,7 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   in.val = result->packvals;
   in.packbits = result->packbits;
   VSA_HIP(hipMemsetAsync(hist.as<uint32_t>() + cells, 0, 4, stream));
-  k_partition_count<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
+  k_partition_count<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
       in, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
       top.as<unsigned long long>());
   VSA_HIP(hipGetLastError());
@@ -2443,7 +2458,7 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
       summary.as<uint64_t>(),
       summary.as<unsigned long long>() + VSA_PART_MAX + 1);
   VSA_HIP(hipGetLastError());
-  k_partition_place<<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(
+  k_partition_place<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
       in, n, nparts, totallength, nblocks, offsets.as<uint64_t>(),
       device_matches);
   VSA_HIP(hipGetLastError());
@@ -2670,7 +2685,7 @@ __global__ void __launch_bounds__(VSA_BLOCK)
 k_split_rows(const uint4 *__restrict__ rows, uint64_t n,
              uint64_t *__restrict__ key, uint64_t *__restrict__ val)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
   if (t < n)
   {
     const uint4 r = rows[t];
@@ -2685,7 +2700,7 @@ k_unpack_pairs(const uint64_t *__restrict__ key,
                const uint64_t *__restrict__ val, uint64_t n,
                uint32_t packbits, vsa_match *__restrict__ out)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * VSA_BLOCK + threadIdx.x;
+  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
   if (t < n)
   {
     const uint64_t k = key[t], v = val[t], mask = (1ull << packbits) - 1;

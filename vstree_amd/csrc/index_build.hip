@@ -60,9 +60,9 @@ struct DevBuf
   }
 };
 
-inline unsigned int gridfor(uint64_t items)
+inline dim3 gridfor(uint64_t items)
 {
-  return (unsigned int) ((items + VB_BLOCK - 1) / VB_BLOCK);
+  return vsa_grid((items + VB_BLOCK - 1) / VB_BLOCK);
 }
 
 } // namespace
@@ -79,7 +79,7 @@ k_pack_keys(const uint8_t *__restrict__ tis, uint64_t n, uint32_t numofchars,
             uint32_t bits, uint32_t H, uint64_t *__restrict__ keys,
             IDX *__restrict__ sa)
 {
-  const uint64_t i = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t i = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (i > n)
   {
     return;
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_initial_heads(const uint64_t *__restrict__ keys, uint64_t count,
                 IDX *__restrict__ head)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j >= count)
   {
     return;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_scatter_rank(const IDX *__restrict__ sa, const IDX *__restrict__ head,
                uint64_t count, IDX *__restrict__ isa)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j < count)
   {
     isa[sa[j]] = head[j];
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_flag_unresolved(const IDX *__restrict__ head, uint64_t count,
                   uint8_t *__restrict__ flag)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j >= count)
   {
     return;
@@ -183,7 +183,7 @@ k_doubling_keys(const IDX *__restrict__ pos, uint64_t m,
                 typename DoublingKey<IDX>::type *__restrict__ ckey,
                 IDX *__restrict__ csuf)
 {
-  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t r = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (r >= m)
   {
     return;
@@ -205,7 +205,7 @@ k_doubling_heads(const typename DoublingKey<IDX>::type *__restrict__ ckey,
                  const IDX *__restrict__ pos, uint64_t m,
                  IDX *__restrict__ newhead)
 {
-  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t r = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (r >= m)
   {
     return;
@@ -221,7 +221,7 @@ k_doubling_writeback(const IDX *__restrict__ pos, const IDX *__restrict__ csuf,
                      IDX *__restrict__ sa, IDX *__restrict__ head,
                      IDX *__restrict__ isa)
 {
-  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t r = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (r >= m)
   {
     return;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_doubling_flags(const IDX *__restrict__ pos, const IDX *__restrict__ newhead,
                  uint64_t m, uint8_t *__restrict__ flag)
 {
-  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t r = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (r >= m)
   {
     return;
@@ -276,7 +276,7 @@ k_lcp_chunks(const uint8_t *__restrict__ tis, uint64_t n,
              IDX *__restrict__ llvval, uint64_t llvcap,
              unsigned long long *__restrict__ llvcount)
 {
-  const uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t c = vsa_bid() * VB_BLOCK + threadIdx.x;
   const uint64_t i0 = c * VB_LCP_CHUNK;
   if (i0 > n)
   {
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_llv_pairs(const IDX *__restrict__ idx, const IDX *__restrict__ val,
             uint64_t m, IDX *__restrict__ llv)
 {
-  const uint64_t r = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t r = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (r < m)
   {
     llv[2 * r] = idx[r];
@@ -362,8 +362,8 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_bck_init(IDX *__restrict__ left, IDX *__restrict__ mid, uint64_t numofcodes)
 {
   // grid-stride: 4^16 codes exceed the 2^32 work-items of one launch
-  for (uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
-       c < numofcodes; c += (uint64_t) gridDim.x * VB_BLOCK)
+  for (uint64_t c = vsa_bid() * VB_BLOCK + threadIdx.x;
+       c < numofcodes; c += vsa_nblocks() * VB_BLOCK)
   {
     left[c] = ~(IDX) 0;
     mid[c] = ~(IDX) 0;
@@ -376,7 +376,7 @@ k_bck_boundaries(const uint8_t *__restrict__ tis, uint64_t n,
                  const IDX *__restrict__ sa, uint32_t pl, uint32_t numofchars,
                  IDX *__restrict__ left, IDX *__restrict__ mid)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j > n)
   {
     return;
@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_bck_finish(const IDX *__restrict__ left, const IDX *__restrict__ mid,
              uint64_t numofcodes, IDX *__restrict__ bck)
 {
-  for (uint64_t c = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
-       c < numofcodes; c += (uint64_t) gridDim.x * VB_BLOCK)
+  for (uint64_t c = vsa_bid() * VB_BLOCK + threadIdx.x;
+       c < numofcodes; c += vsa_nblocks() * VB_BLOCK)
   {
     const IDX l = left[c];
     IDX m = mid[c];
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_bwt(const uint8_t *__restrict__ tis, const IDX *__restrict__ sa, uint64_t n,
       uint8_t *__restrict__ bwt)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j <= n)
   {
     const IDX s = sa[j];
@@ -649,8 +649,14 @@ int build_tables(vsa_index *ix)
     }
     flag.free();
     uint64_t h = H;
+    const char *trace = getenv("VSA_BUILD_TRACE");
     while (m > 0)
     {
+      if (trace != nullptr)
+      {
+        fprintf(stderr, "vsa build: %lu suffixes tied after %lu symbols\n",
+                (unsigned long) m, (unsigned long) h);
+      }
       DevBuf ckey, ckey2, csuf, csuf2, newhead, rflag, pos2, t2;
       if (ckey.alloc(m * sizeof(CK)) || ckey2.alloc(m * sizeof(CK)) ||
           csuf.alloc(m * sizeof(IDX)) || csuf2.alloc(m * sizeof(IDX)) ||
@@ -884,7 +890,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_sti1_runstarts(const uint8_t *__restrict__ lcp, uint64_t count, uint32_t pl,
                  IDX *__restrict__ runstart)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j < count)
   {
     runstart[j] = (j == 0 || lcp[j] < (uint8_t) pl) ? (IDX) j : (IDX) 0;
@@ -896,7 +902,7 @@ __global__ void __launch_bounds__(VB_BLOCK)
 k_sti1_scatter(const IDX *__restrict__ sa, const IDX *__restrict__ runstart,
                uint64_t count, uint8_t *__restrict__ sti1)
 {
-  const uint64_t j = (uint64_t) blockIdx.x * VB_BLOCK + threadIdx.x;
+  const uint64_t j = vsa_bid() * VB_BLOCK + threadIdx.x;
   if (j < count)
   {
     const uint64_t d = j - runstart[j];

@@ -35,7 +35,7 @@ const int kSlots = 3;
 __global__ void k_pipeline_starts(uint64_t *start, uint64_t *length,
                                   uint64_t nq, uint64_t m)
 {
-  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = vsa_bid() * blockDim.x + threadIdx.x;
   if (i < nq)
   {
     start[i] = i * m;

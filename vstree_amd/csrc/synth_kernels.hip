@@ -13,7 +13,7 @@ __device__ __forceinline__ uint64_t sm64_mix(uint64_t z)
 __global__ void __launch_bounds__(256)
 k_synth_genome(uint64_t seed, uint64_t n, uint8_t *__restrict__ codes)
 {
-  const uint64_t i0 = ((uint64_t) blockIdx.x * 256 + threadIdx.x) * 16;
+  const uint64_t i0 = (vsa_bid() * 256 + threadIdx.x) * 16;
   if (i0 >= n)
   {
     return;
@@ -46,7 +46,7 @@ k_synth_queries(const uint8_t *__restrict__ genome,
                 const uint8_t *__restrict__ step, uint64_t nq, uint32_t m,
                 uint8_t *__restrict__ queries)
 {
-  const uint64_t t = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+  const uint64_t t = vsa_bid() * 256 + threadIdx.x;
   if (t >= nq * (uint64_t) m)
   {
     return;
@@ -73,7 +73,7 @@ extern "C" int vsa_synth_genome_device(uint64_t seed, uint64_t n,
     return 0;
   }
   const uint64_t items = (n + 15) / 16;
-  k_synth_genome<<<(unsigned int) ((items + 255) / 256), 256>>>(
+  k_synth_genome<<<vsa_grid((items + 255) / 256), 256>>>(
       seed, n, (uint8_t *) device_codes);
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipDeviceSynchronize());
@@ -106,7 +106,7 @@ extern "C" int vsa_synth_queries_device(const void *device_genome, uint64_t n,
   VSA_HIP(hipMemcpy(dsub, substidx, nq * 4, hipMemcpyHostToDevice));
   VSA_HIP(hipMemcpy(dstep, step, nq, hipMemcpyHostToDevice));
   const uint64_t items = nq * (uint64_t) m;
-  k_synth_queries<<<(unsigned int) ((items + 255) / 256), 256>>>(
+  k_synth_queries<<<vsa_grid((items + 255) / 256), 256>>>(
       (const uint8_t *) device_genome, dpos, dsub, dstep, nq, m,
       (uint8_t *) device_queries);
   VSA_HIP(hipGetLastError());

@@ -221,6 +221,36 @@ void vsa_dev_forget_stream(hipStream_t stream);
 // out of memory
 hipError_t vsa_hip_malloc(void **ptr, size_t bytes);
 
+// One grid dimension holds fewer than 2^32 work-items (the dispatch packet
+// counts them in 32 bits): a launch over more blocks than VSA_GRID_X folds them
+// into (x, y), and every kernel takes its block number from vsa_bid().  Blocks
+// beyond the last item find nothing to do -- each kernel checks its bounds.
+#define VSA_GRID_X (1u << 22)
+inline dim3 vsa_grid(uint64_t blocks)
+{
+  if (blocks <= VSA_GRID_X)
+  {
+    return dim3((unsigned int) (blocks > 0 ? blocks : 1));
+  }
+  return dim3(VSA_GRID_X, (unsigned int) ((blocks + VSA_GRID_X - 1) / VSA_GRID_X));
+}
+// blocks such a launch really has (for tables with one entry per block)
+inline uint64_t vsa_grid_blocks(uint64_t blocks)
+{
+  const dim3 g = vsa_grid(blocks);
+  return (uint64_t) g.x * g.y;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint64_t vsa_bid()
+{
+  return (uint64_t) blockIdx.y * gridDim.x + blockIdx.x;
+}
+__device__ __forceinline__ uint64_t vsa_nblocks()
+{
+  return (uint64_t) gridDim.x * gridDim.y;
+}
+#endif
+
 // builds the deep-locate tables bck2/esa8 from tis/suf/lcp (esa_search.hip);
 // a no-op for alphabets beyond 4 symbols, 64-bit tables or VSA_NO_ESA8=1
 int vsa_index_make_esa8(vsa_index *ix);
