@@ -335,6 +335,7 @@ extern "C" void vsa_index_close(vsa_index *ix)
   (void) hipFree(ix->slot16);
   (void) hipFree(ix->tis2);
   (void) hipFree(ix->spec64);
+  (void) hipFree(ix->isa32);
   if (ix->stream != nullptr)
   {
     vsa_dev_forget_stream(ix->stream);

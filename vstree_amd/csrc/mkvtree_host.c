@@ -216,37 +216,66 @@ static int writefile(const char *indexname, const char *suffix,
   return 0;
 }
 
-/* table with 32-bit device entries written as `bits`-wide integers */
+/* entry i of a table of w-byte integers (w = 4 or 8: the width of the device
+   tables, 8 for texts of 2^32 symbols and more) */
+static uint64_t geti(const void *v, uint32_t w, uint64_t i)
+{
+  return w == 4 ? (uint64_t) ((const uint32_t *) v)[i]
+                : ((const uint64_t *) v)[i];
+}
+
+static void seti(void *v, uint32_t w, uint64_t i, uint64_t x)
+{
+  if (w == 4)
+  {
+    ((uint32_t *) v)[i] = (uint32_t) x;
+  } else
+  {
+    ((uint64_t *) v)[i] = x;
+  }
+}
+
+/* table of w-byte entries written as `bits`-wide integers */
 static int writeintegers(const char *indexname, const char *suffix,
-                         const uint32_t *v, uint64_t count, uint32_t bits)
+                         const void *v, uint32_t w, uint64_t count,
+                         uint32_t bits)
 {
   int rc;
+  uint64_t i;
+  void *out;
 
-  if (bits == 32)
+  if (bits == 8 * w)
   {
-    return writefile(indexname, suffix, v, (size_t) count * 4);
+    return writefile(indexname, suffix, v, (size_t) count * w);
   }
+  out = malloc((size_t) (count ? count : 1) * (bits / 8));
+  if (out == NULL)
   {
-    uint64_t i, *w = (uint64_t *) malloc((size_t) (count ? count : 1) * 8);
-    if (w == NULL)
+    snprintf(vsa_errbuf(), ERRSIZE, "out of memory");
+    return -1;
+  }
+  for (i = 0; i < count; i++)
+  {
+    const uint64_t x = geti(v, w, i);
+    if (bits == 32 && (x >> 32) != 0)
     {
-      snprintf(vsa_errbuf(), ERRSIZE, "out of memory");
+      snprintf(vsa_errbuf(), ERRSIZE,
+               "integersize 32 cannot hold the entries of %s.%s", indexname,
+               suffix);
+      free(out);
       return -1;
     }
-    for (i = 0; i < count; i++)
-    {
-      w[i] = v[i];
-    }
-    rc = writefile(indexname, suffix, w, (size_t) count * 8);
-    free(w);
+    seti(out, bits / 8, i, x);
   }
+  rc = writefile(indexname, suffix, out, (size_t) count * (bits / 8));
+  free(out);
   return rc;
 }
 
 /* kurtz/mkskip.c:51-96: skp[i] = last index up to which the lcp values stay
    >= lcp[i] (next smaller value to the right, minus one) */
-static int makeskiptable(uint32_t *skp, const uint8_t *lcp,
-                         const uint32_t *llv, uint64_t n)
+static int makeskiptable(void *skp, const uint8_t *lcp, const void *llv,
+                         uint32_t w, uint64_t n)
 {
   uint64_t i, top = 0, exception = 0, cap = 1024;
   uint64_t *depth = (uint64_t *) malloc(cap * 8),
@@ -267,11 +296,11 @@ static int makeskiptable(uint32_t *skp, const uint8_t *lcp,
     uint64_t cur = lcp[i];
     if (cur == 255)
     {
-      cur = llv[2 * (exception++) + 1];
+      cur = geti(llv, w, 2 * (exception++) + 1);
     }
     while (cur < depth[top - 1])
     {
-      skp[step[top - 1]] = (uint32_t) (i - 1);
+      seti(skp, w, step[top - 1], i - 1);
       top--;
     }
     if (top == cap)
@@ -291,7 +320,7 @@ static int makeskiptable(uint32_t *skp, const uint8_t *lcp,
   }
   while (top > 0)
   {
-    skp[step[top - 1]] = (uint32_t) n;
+    seti(skp, w, step[top - 1], n);
     top--;
   }
   free(depth);
@@ -311,7 +340,8 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
   vsa_index *ix = NULL;
   vsa_index_info info;
   uint8_t *lcp = NULL, *bwt = NULL, *sti1 = NULL;
-  uint32_t *suf = NULL, *llv = NULL, *bck = NULL, *skp = NULL;
+  void *suf = NULL, *llv = NULL, *bck = NULL, *skp = NULL;
+  uint32_t w = 4; /* bytes per entry of the device tables */
   int rc = -1;
   FILE *prj;
   char path[4096 + 32];
@@ -377,12 +407,13 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
   {
     goto done;
   }
-  suf = (uint32_t *) malloc((size_t) (t.n + 1) * 4);
+  w = info.device_integersize / 8;
+  suf = malloc((size_t) (t.n + 1) * w);
   lcp = (uint8_t *) malloc((size_t) t.n + 1);
   bwt = (uint8_t *) malloc((size_t) t.n + 1);
   sti1 = (uint8_t *) malloc((size_t) t.n + 1);
-  llv = (uint32_t *) malloc((size_t) (2 * info.largelcpvalues + 1) * 4);
-  bck = (uint32_t *) malloc((size_t) (2 * info.numofcodes) * 4);
+  llv = malloc((size_t) (2 * info.largelcpvalues + 1) * w);
+  bck = malloc((size_t) (2 * info.numofcodes) * w);
   if (suf == NULL || lcp == NULL || bwt == NULL || sti1 == NULL ||
       llv == NULL || bck == NULL)
   {
@@ -418,7 +449,7 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
     }
     for (k = 0; k <= t.n; k++)
     {
-      if (suf[k] == 0)
+      if (geti(suf, w, k) == 0)
       {
         longest = k; /* determinelongest, mkvprocess.c:857-873 */
         break;
@@ -433,9 +464,9 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
     }
     for (k = 0; k < info.largelcpvalues; k++)
     {
-      if (llv[2 * k + 1] > maxbranchdepth)
+      if (geti(llv, w, 2 * k + 1) > maxbranchdepth)
       {
-        maxbranchdepth = llv[2 * k + 1];
+        maxbranchdepth = geti(llv, w, 2 * k + 1);
       }
     }
     while (prefix < t.n && t.tis[prefix] >= VSA_WILDCARD)
@@ -481,17 +512,17 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
       writefile(indexname, "lcp", lcp, (size_t) t.n + 1) != 0 ||
       writefile(indexname, "bwt", bwt, (size_t) t.n + 1) != 0 ||
       writefile(indexname, "sti1", sti1, (size_t) t.n + 1) != 0 ||
-      writeintegers(indexname, "suf", suf, t.n + 1, integersize) != 0 ||
-      writeintegers(indexname, "llv", llv, 2 * info.largelcpvalues,
+      writeintegers(indexname, "suf", suf, w, t.n + 1, integersize) != 0 ||
+      writeintegers(indexname, "llv", llv, w, 2 * info.largelcpvalues,
                     integersize) != 0 ||
-      writeintegers(indexname, "bck", bck, 2 * info.numofcodes,
+      writeintegers(indexname, "bck", bck, w, 2 * info.numofcodes,
                     integersize) != 0)
   {
     goto done;
   }
   /* .sds and .ssp hold Uint values, too */
   {
-    uint32_t *tmp = (uint32_t *) malloc((size_t) (t.numseq + 2) * 4);
+    uint64_t *tmp = (uint64_t *) malloc((size_t) (t.numseq + 2) * 8);
     if (tmp == NULL)
     {
       snprintf(vsa_errbuf(), ERRSIZE, "out of memory");
@@ -499,16 +530,16 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
     }
     for (i = 0; i <= t.numseq; i++)
     {
-      tmp[i] = (uint32_t) t.sds[i];
+      tmp[i] = t.sds[i];
     }
-    rc = writeintegers(indexname, "sds", tmp, t.numseq + 1, integersize);
+    rc = writeintegers(indexname, "sds", tmp, 8, t.numseq + 1, integersize);
     for (i = 0; i + 1 < t.numseq; i++)
     {
-      tmp[i] = (uint32_t) t.ssp[i];
+      tmp[i] = t.ssp[i];
     }
     if (rc == 0 && t.numseq > 1)
     {
-      rc = writeintegers(indexname, "ssp", tmp, t.numseq - 1, integersize);
+      rc = writeintegers(indexname, "ssp", tmp, 8, t.numseq - 1, integersize);
     }
     free(tmp);
     if (rc != 0)
@@ -520,14 +551,14 @@ int vsa_mkvtree(const char *const *dbfiles, uint32_t numofdbfiles,
   }
   if (withskp)
   {
-    skp = (uint32_t *) malloc((size_t) (t.n + 1) * 4);
+    skp = malloc((size_t) (t.n + 1) * w);
     if (skp == NULL)
     {
       snprintf(vsa_errbuf(), ERRSIZE, "out of memory");
       goto done;
     }
-    if (makeskiptable(skp, lcp, llv, t.n) != 0 ||
-        writeintegers(indexname, "skp", skp, t.n + 1, integersize) != 0)
+    if (makeskiptable(skp, lcp, llv, w, t.n) != 0 ||
+        writeintegers(indexname, "skp", skp, w, t.n + 1, integersize) != 0)
     {
       goto done;
     }

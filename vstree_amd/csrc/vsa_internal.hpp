@@ -118,6 +118,9 @@ struct vsa_index
   // which the reference's uniqueness test for lcp >= 255 (fquery.c:352) can
   // call a repeated match unique; 0: cannot happen; -1: not looked at yet
   mutable int lcpquirk;
+  // inverse suffix array, isa32[suf[i]] = i: made by the first call that wants
+  // it (tandem repeats, selfmatch_search.inc) and kept; nullptr before
+  mutable uint32_t *isa32;
 
   template <typename IDX>
   DevIndex<IDX> view() const
