@@ -832,38 +832,32 @@ struct DeepHit
   bool notleftmax;  // see vsa_locate_deep, qleft
 };
 
-template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
-          typename IDX = uint32_t>
-__device__ __forceinline__ int
-vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
-                const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
-                uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
-                uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
-                uint32_t pqoff = 0)
+// What the first round trip of the deep locate brings: the bounds of the deep
+// bucket of the query's first D symbols with the bucket's first entries, and
+// the query's key symbols.  Two-phase callers (k_query_search_planned2) look
+// at it, finish most searches on the spot and pass the others on.
+struct DeepFront
 {
-  // PQ: the whole query is in *pq (vsa_pq_stage / vsa_pq_load) and the
-  // suffix searched starts at its offset pqoff; `query` points at the bytes
-  // of that suffix for the lanes that fall back to them
-  // qleft < 0x100 (MEM enumeration, needleft = the least length): the query
-  // symbol in front of this suffix.  Only members of the deep bucket share D
-  // or more symbols with the query; in a bucket of up to four their keys tell
-  // which of them can reach the least length.  If every one of those has
-  // qleft in front (the symbol is in the entry), no match of this work-item
-  // is left maximal and nothing will be reported whatever the lengths
-  // (leftrightsubmatch, fquery.c:139-270 -> PROCESSSUFFIX :54-81):
-  // hit.notleftmax is set and the comparison on the text -- the expensive
-  // part for reads that match end to end at every offset -- is skipped.
-  // maxlcp is then only a lower bound.
-  // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
-  // of at least this length (the MUM test).
+  uint64_t raw;                  // word 0 of the slot as loaded
+  uint64_t left;                 // first suffix of the bucket
+  uint64_t first, second, third; // esa8[left..] from the fused table (or 0)
+  uint32_t cnt, qkey, limit;     // suffixes in the bucket; key symbols, how
+                                 // many of them the query has
+  int state;                     // VSA_LOC_NONE / FOUND (= go on) / SLOW
+};
+
+template <bool PQ = false, typename IDX = uint32_t>
+__device__ __forceinline__ void
+vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
+               uint32_t querylen, DeepFront &f,
+               const PackedQuery *pq = nullptr, uint32_t pqoff = 0)
+{
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
-  int state = VSA_LOC_NONE;
-  // first suffix of the deep bucket: a register pair only for wide tables
-  typename std::conditional<sizeof(IDX) == 4, uint32_t, uint64_t>::type dl = 0;
-  uint32_t cnt = 0, qkey = 0, limit = 0;
-  uint64_t first = 0, second = 0, third = 0; // esa8[dl..] from the fused table
-
+  f.state = VSA_LOC_NONE;
+  f.raw = f.left = 0;
+  f.cnt = f.qkey = f.limit = 0;
+  f.first = f.second = f.third = 0;
   if (active)
   {
     uint32_t valid = 32; // leading regular symbols inside the query
@@ -907,18 +901,18 @@ vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
     }
     if (valid < ix.pl)
     {
-      state = VSA_LOC_NONE; // qgram2code fails or query shorter than pl
+      f.state = VSA_LOC_NONE; // qgram2code fails or query shorter than pl
     } else if (valid < D)
     {
-      state = VSA_LOC_SLOW;
+      f.state = VSA_LOC_SLOW;
     } else
     {
       const uint64_t code = S >> (64 - 2 * D);
-      qkey = (uint32_t) (S >> (64 - 2 * D - 2 * VSA_KEYSYMS)) & VSA_KEYMASK;
-      limit = valid - D;
-      if (limit > VSA_KEYSYMS)
+      f.qkey = (uint32_t) (S >> (64 - 2 * D - 2 * VSA_KEYSYMS)) & VSA_KEYMASK;
+      f.limit = valid - D;
+      if (f.limit > VSA_KEYSYMS)
       {
-        limit = VSA_KEYSYMS;
+        f.limit = VSA_KEYSYMS;
       }
       // (left, mid) of the deep bucket -- with the first entry of the
       // bucket if the fused table is there: one load
@@ -928,25 +922,61 @@ vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
         const uint64_t *sp = ix.slot16 + (uint64_t) ix.slotwords * code;
         const vsa_u128 sl = vsa_load16(sp);
         b = sl.lo;
-        first = sl.hi;
+        f.first = sl.hi;
         if (ix.slotwords == 4)
         {
           // the other half of the 32-byte slot: same 64-byte sector
           const vsa_u128 sm = vsa_load16(sp + 2);
-          second = sm.lo;
-          third = sm.hi;
+          f.second = sm.lo;
+          f.third = sm.hi;
         }
       } else
       {
         b = vsa_ld_entry(reinterpret_cast<const uint64_t *>(ix.bck2) + code,
                          nt);
       }
-      uint64_t bleft;
-      vsa_slotbounds<IDX>(b, bleft, cnt);
-      dl = (decltype(dl)) bleft;
-      state = (cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
+      f.raw = b;
+      vsa_slotbounds<IDX>(b, f.left, f.cnt);
+      f.state = (f.cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
     }
   }
+}
+
+// the deep locate from a front that is at hand (all lanes, see below)
+template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
+          typename IDX = uint32_t>
+__device__ __forceinline__ int
+vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
+                     const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
+                     uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
+                     uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
+                     uint32_t pqoff = 0)
+{
+  // PQ: the whole query is in *pq (vsa_pq_stage / vsa_pq_load) and the
+  // suffix searched starts at its offset pqoff; `query` points at the bytes
+  // of that suffix for the lanes that fall back to them
+  // qleft < 0x100 (MEM enumeration, needleft = the least length): the query
+  // symbol in front of this suffix.  Only members of the deep bucket share D
+  // or more symbols with the query; in a bucket of up to four their keys tell
+  // which of them can reach the least length.  If every one of those has
+  // qleft in front (the symbol is in the entry), no match of this work-item
+  // is left maximal and nothing will be reported whatever the lengths
+  // (leftrightsubmatch, fquery.c:139-270 -> PROCESSSUFFIX :54-81):
+  // hit.notleftmax is set and the comparison on the text -- the expensive
+  // part for reads that match end to end at every offset -- is skipped.
+  // maxlcp is then only a lower bound.
+  // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
+  // of at least this length (the MUM test).
+  const bool nt = (ix.tune & 1u) != 0;
+  const uint32_t D = ix.D;
+  int state = f.state;
+  // first suffix of the deep bucket: a register pair only for wide tables
+  const typename std::conditional<sizeof(IDX) == 4, uint32_t, uint64_t>::type
+      dl = (typename std::conditional<sizeof(IDX) == 4, uint32_t,
+                                      uint64_t>::type) f.left;
+  const uint32_t cnt = f.cnt, qkey = f.qkey, limit = f.limit;
+  const uint64_t first = f.first, second = f.second, third = f.third;
+
   const bool searching = state == VSA_LOC_FOUND;
   // only the first `limit` key symbols of the query exist
   const uint32_t qk = qkey >> (2 * (VSA_KEYSYMS - limit));
@@ -1171,6 +1201,22 @@ vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
     maxlcp = lcplen;
   }
   return state;
+}
+
+template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
+          typename IDX = uint32_t>
+__device__ __forceinline__ int
+vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
+                const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
+                uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
+                uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
+                uint32_t pqoff = 0)
+{
+  DeepFront f;
+  vsa_deep_front<PQ>(ix, active, query, querylen, f, pq, pqoff);
+  return vsa_locate_deep_from<AHEAD, DEFER, PQ>(ix, f, query, querylen, maxlcp,
+                                                w, hit, needleft, qleft, pq,
+                                                pqoff);
 }
 
 // 64-lane helpers ----------------------------------------------------------

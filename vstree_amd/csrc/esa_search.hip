@@ -1323,13 +1323,31 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       deep = deep || deepok;
       if (fromplan)
       {
-        k_query_search_planned<IDX, 256>
-            <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
-                ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
-                wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
-                rawkeys.as<uint64_t>(), shardcap, nshards - 1,
-                cursor.as<unsigned long long>(), packbits, valbits,
-                blocksum.as<unsigned long long>());
+        // VSA_K2_TWOPHASE=1 (experiment, fused 16-byte slots): work-items
+        // the slot finishes leave after one round trip, the others are
+        // compacted per wavefront (k_query_search_planned2).  Round 2, same
+        // box: 1.74 ms against 1.50-1.55 ms for the one-phase kernel.
+        const char *twophase = getenv("VSA_K2_TWOPHASE");
+        if (ix.slot16 != nullptr && ix.slotwords == 2 && twophase != nullptr &&
+            strcmp(twophase, "1") == 0)
+        {
+          k_query_search_planned2<IDX, 256>
+              <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
+                  ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+                  wcount.as<uint32_t>(), searchlength,
+                  rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
+                  nshards - 1, cursor.as<unsigned long long>(), packbits,
+                  valbits, blocksum.as<unsigned long long>());
+        } else
+        {
+          k_query_search_planned<IDX, 256>
+              <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
+                  ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+                  wcount.as<uint32_t>(), searchlength,
+                  rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
+                  nshards - 1, cursor.as<unsigned long long>(), packbits,
+                  valbits, blocksum.as<unsigned long long>());
+        }
       } else if (deep && nwork > 0)
       {
         bool deferred = false;
