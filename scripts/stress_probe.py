@@ -7,6 +7,8 @@ list (-complete, MEM, -mum cand, -mum) must equal the oracle's, order
 included (MEM: under -qspeedup 0 and under the default -qspeedup 2; every
 third round takes a small prefixlength and more low-complexity stretches so
 that buckets hold more than 255 suffixes and stitab1 saturates).
+VSA_STRESS_TABLES=1 also compares the tables the GPU builder wrote with the
+CPU restatement's (with VSA_FORCE_WIDE=1: the 64-bit builder).
 usage: stress_probe.py [ROUNDS] [SEED]"""
 import os
 import sys
@@ -49,6 +51,13 @@ for rnd in range(rounds):
                           for s in seqs])[:-1].astype(np.uint8)
     gi = V.Index.build(tis, 4, 0 if rnd % 3 else int(rng.integers(1, 6)))
     tb = gi.download()
+    if os.environ.get("VSA_STRESS_TABLES") == "1":
+        # the builder itself (e.g. under VSA_FORCE_WIDE=1) against the CPU
+        # restatement of mkvtree's tables
+        want = H.oracle_build_index(tis, 4, gi.info().prefixlength)
+        for k in ("suf", "lcp", "llv", "bck", "bwt"):
+            assert np.array_equal(tb[k].astype(np.uint64),
+                                  getattr(want, k).astype(np.uint64)), (rnd, k)
     host = H.Index(len(tis), gi.info().prefixlength, 4, tb["tis"], tb["suf"],
                    tb["lcp"], tb["llv"], tb["bck"], tb["bwt"],
                    H.sti1_from_tables(tb["suf"], tb["lcp"],
