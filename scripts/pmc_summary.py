@@ -74,8 +74,8 @@ def main():
             # gfx950 (MI355X_MICROARCH.md, HBM counters): doubled for them.
             fams = {}
             for key, pattern, factor in (
-                    ("k_mum_first", "k_mum_first<unsigned int, true>", 1),
-                    ("k_complete_search", "k_complete_search<unsigned int, true>", 1),
+                    ("k_mum_first", "k_mum_first<unsigned int, true", 1),
+                    ("k_complete_search", "k_complete_search<unsigned int, true, true", 1),
                     ("k_query_search_mem", "k_query_search<unsigned int, false, true", 1),
                     ("k_apm_banded", "k_apm_banded", 1),
                     ("k_selfmum_peaks", "k_selfmum_peaks", 2)):
