@@ -917,3 +917,33 @@ def test_mum_filter_runs_of_equal_dbstart(V):
         got = V.findquerymatches(gi, gpu_queries(V, q), 20, mum=True).fetch()
         want = H.oracle_querymatches(host, q, 20, mum=True, speedup=0)
         assert np.array_equal(got, want), runs[0]
+
+
+def test_inconsistent_tables_are_refused_on_upload(V):
+    """index files anybody may have written: entries that point outside the
+    tables are an error return of vsa_index_from_tables, not a GPU fault in
+    the search kernels"""
+    idx, _ = H.load_case("micro")
+    i = idx.as_width(64)
+
+    def upload(**changed):
+        t = dict(suf=i.suf.copy(), bck=i.bck.copy(), llv=i.llv.copy())
+        for k, f in changed.items():
+            f(t[k])
+        return V.Index.from_tables(i.n, i.prefixlength, i.numofchars, i.tis,
+                                   t["suf"], i.lcp, t["llv"], t["bck"], i.bwt,
+                                   i.querysepposition, i.hasqueries)
+
+    upload().close()                                   # the real tables pass
+
+    def beyond(a):
+        a[len(a) // 2] = i.n + 5
+
+    def swapped(a):
+        a[3], a[4] = a[4] + 2, a[3]
+
+    for what, kw in (("suf", dict(suf=beyond)), ("bck", dict(bck=beyond)),
+                     ("bck", dict(bck=swapped))):
+        with pytest.raises(V.VsaError) as e:
+            upload(**kw)
+        assert e.value.code == -2 and what in e.value.message, kw

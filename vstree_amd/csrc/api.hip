@@ -151,6 +151,60 @@ uint64_t powu64(uint64_t b, uint32_t e)
   return r;
 }
 
+// Uploaded tables come from files anybody may have written: entries that
+// point outside the tables would turn into out-of-bounds reads in the search
+// kernels (a GPU fault, not an error return).  One pass over suf, bck and llv:
+// bit 0 of *bad: a suf entry beyond n; bit 1: bck not non-decreasing or beyond
+// n + 1; bit 2: an llv index beyond n or not increasing.
+template <typename IDX>
+__global__ void __launch_bounds__(256)
+k_validate_tables(const IDX *__restrict__ suf, uint64_t n,
+                  const IDX *__restrict__ bck, uint64_t nbck,
+                  const IDX *__restrict__ llv, uint64_t nllv,
+                  unsigned int *__restrict__ bad)
+{
+  const uint64_t stride = vsa_nblocks() * 256;
+  unsigned int mine = 0;
+  for (uint64_t i = vsa_bid() * 256 + threadIdx.x; i <= n; i += stride)
+  {
+    mine |= ((uint64_t) suf[i] > n) ? 1u : 0u;
+  }
+  if (bck != nullptr)
+  {
+    for (uint64_t i = vsa_bid() * 256 + threadIdx.x; i < nbck; i += stride)
+    {
+      const uint64_t v = bck[i];
+      mine |= (v > n + 1 || (i > 0 && (uint64_t) bck[i - 1] > v)) ? 2u : 0u;
+    }
+  }
+  for (uint64_t i = vsa_bid() * 256 + threadIdx.x; i < nllv; i += stride)
+  {
+    const uint64_t v = llv[2 * i];
+    mine |= (v > n || (i > 0 && (uint64_t) llv[2 * i - 2] >= v)) ? 4u : 0u;
+  }
+  if (mine != 0)
+  {
+    atomicOr(bad, mine);
+  }
+}
+
+template <typename IDX>
+int validate_tables(const vsa_index *ix, unsigned int *verdict)
+{
+  unsigned int *dbad = nullptr;
+  VSA_HIP(vsa_hip_malloc((void **) &dbad, 4));
+  VSA_HIP(hipMemsetAsync(dbad, 0, 4, ix->stream));
+  k_validate_tables<IDX><<<4096, 256, 0, ix->stream>>>(
+      (const IDX *) ix->suf, ix->n, (const IDX *) ix->bck,
+      2 * ix->numofcodes, (const IDX *) ix->llv, ix->nllv, dbad);
+  VSA_HIP(hipGetLastError());
+  VSA_HIP(hipMemcpyAsync(verdict, dbad, 4, hipMemcpyDeviceToHost,
+                         ix->stream));
+  VSA_HIP(hipStreamSynchronize(ix->stream));
+  (void) hipFree(dbad);
+  return 0;
+}
+
 } // namespace
 
 // allocates the device tables of an index of the given shape; contents are
@@ -435,6 +489,24 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
                       ix->llv, s))
   {
     return fail(-100);
+  }
+  {
+    unsigned int bad = 0;
+    if (ix->isize == 4 ? validate_tables<uint32_t>(ix, &bad)
+                       : validate_tables<uint64_t>(ix, &bad))
+    {
+      return fail(-100);
+    }
+    if (bad != 0)
+    {
+      VSA_ERROR("inconsistent index tables:%s%s%s",
+                (bad & 1u) ? " a suf entry beyond the text;" : "",
+                (bad & 2u) ? " bck not non-decreasing or beyond the table;"
+                           : "",
+                (bad & 4u) ? " llv indices not increasing or beyond the table;"
+                           : "");
+      return fail(-2);
+    }
   }
   if (t->bck != nullptr && vsa_index_make_esa8(ix) != 0)
   {

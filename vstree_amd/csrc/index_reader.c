@@ -272,9 +272,30 @@ int vsa_index_open(const char *indexname, int device, vsa_index **index)
              indexname, (unsigned long) prj.prefixlength);
     return -1;
   }
+  /* sizes that cannot be an index (and whose products below would wrap) */
+  if (prj.totallength >= (1ull << 40) ||
+      prj.largelcpvalues > prj.totallength + 1 ||
+      (prj.integersize != 32 && prj.integersize != 64))
+  {
+    snprintf(vsa_errbuf(), ERRSIZE,
+             "%s.prj: totallength=%lu largelcpvalues=%lu integersize=%lu: "
+             "not the sizes of an index", indexname,
+             (unsigned long) prj.totallength,
+             (unsigned long) prj.largelcpvalues,
+             (unsigned long) prj.integersize);
+    return -1;
+  }
   for (k = 0; k < prj.prefixlength; k++)
   {
     numofcodes *= numofchars;
+    if (numofcodes > (1ull << 36))
+    {
+      snprintf(vsa_errbuf(), ERRSIZE,
+               "%s.prj: prefixlength=%lu is too large for %lu characters",
+               indexname, (unsigned long) prj.prefixlength,
+               (unsigned long) numofchars);
+      return -1;
+    }
   }
   w = prj.integersize / 8;
   memset(&tis, 0, sizeof tis);
