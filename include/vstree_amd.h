@@ -274,6 +274,11 @@ int vsa_findmumcandidates(const vsa_index *index, const vsa_queries *queries,
   then writes rows of the two words (half the bytes of the exchange);
   vsa_result_fetch / vsa_result_copy_device deliver it as records,
   vsa_result_device_matches is NULL for it.
+  Limits of the pair form: queries shorter than 65 535 symbols and global
+  query numbers below 2^48; a batch beyond them is answered with -2 and a
+  message, and the caller takes the record form -- vsa_findmumcandidates,
+  vsa_result_partition on records, vsa_mumuniqueinquery_range -- as
+  vsa_multi_findmatches (multi_gpu.cpp) does by itself.
 */
 int vsa_findmumcandidates_packed(const vsa_index *index,
                                  const vsa_queries *queries,
