@@ -9,7 +9,9 @@ with 64-bit suf/bck/llv, deep-locate tables in their wide form, searched by
   * planted answers: every unmodified read is found where it was cut, and
     reads cut from positions >= 2^32 are among them;
   * the reference's MUM filter (CPU) over all GPU candidates == the GPU's
-    MUM list; sampled MUMs are maximal exact matches in the text.
+    MUM list; sampled MUMs are maximal exact matches in the text;
+  * the scan over the index itself (`vmatch -mum IDX`, the two halves of the
+    text as database and query), whole and in 8 ranges, against the oracle.
 VSA_WIDE_BP / VSA_WIDE_QUERIES change the size; VSA_WIDE_BP=0 skips the
 module (it needs ~230 GB of HBM while the derived tables are made)."""
 import os
@@ -35,6 +37,14 @@ def world(V):
     dg = V.device_malloc(N + 64)
     V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, N, dg, 0))
     pos, sub, step = V.synth_query_plan(N, NQ, M)
+    # a separator in the middle (for the scan over the index itself), at a
+    # position no read covers
+    import ctypes as C
+    sep = N // 2
+    while ((pos <= sep) & (pos + M > sep)).any():
+        sep += 1
+    V.device_upload(C.c_void_p(dg.value + sep),
+                    np.array([H.SEPARATOR], np.uint8))
     dq = V.device_malloc(NQ * M + 64)
     V._check(V.lib.vsa_synth_queries_device(dg, N, pos.ctypes.data,
                                             sub.ctypes.data, step.ctypes.data,
@@ -48,7 +58,7 @@ def world(V):
     host = H.Index(N, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
                    t["llv"], t["bck"], t["bwt"], None)
     yield dict(index=index, queries=queries, host=host, pos=pos, sub=sub,
-               step=step, info=info)
+               step=step, info=info, sep=sep)
     index.close()
     V.lib.vsa_device_trim(0)
 
@@ -125,3 +135,25 @@ def test_planted_answers_and_global_mum_filter(V, world):
         assert np.array_equal(tis[s:s + ln], hq[qo:qo + ln])
         assert qo + ln == M or s + ln == N or tis[s + ln] != hq[qo + ln]
         assert qo == 0 or s == 0 or tis[s - 1] != hq[qo - 1]
+
+
+def test_self_index_scan_on_the_wide_index(V, world):
+    """vmatch -mum on an index that holds two "genomes" (the first and the
+    second half of the text, vsa_index_set_queryseparator): the streaming
+    scan over suf/lcp/bwt with positions beyond 2^32, whole and by ranges,
+    against the oracle on the same tables"""
+    from vstree_amd import sharding as S
+    ix, host = world["index"], world["host"]
+    sep = world["sep"]
+    ix.set_queryseparator(sep)
+    host.querysepposition, host.hasqueries = sep, True
+    L = 22
+    whole = V.findmaximaluniquematches(ix, L).fetch()
+    want = H.oracle_selfmum(host, L)
+    assert len(want) > 1000
+    assert np.array_equal(whole, want)
+    if N + 1 >= 1 << 32:
+        assert (whole["queryseq"] >= 1 << 32).sum() > len(whole) // 50
+    parts = [V.findmaximaluniquematches(ix, L, *S.selfmum_range(N, r, 8))
+             .fetch() for r in range(8)]
+    assert np.array_equal(np.concatenate(parts), whole)

@@ -1649,11 +1649,6 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   double searchms = 0;
 
   res->stats.searches = jhi > jlo ? jhi - jlo : 0;
-  if (n + 1 >= 0xFFFFFFFFull)
-  {
-    VSA_ERROR("self-index MUM scan: texts beyond 2^32 are not supported");
-    return -3;
-  }
   DevBuf summary;
   if (cursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
       doff.alloc(nshards * 8) || dcount.alloc(8) || summary.alloc(4 * 8))
@@ -1663,7 +1658,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   tall.start();
   for (int attempt = 0; attempt < 2; attempt++)
   {
-    if (rawpos.alloc(nshards * shardcap * 4))
+    if (rawpos.alloc(nshards * shardcap * sizeof(IDX)))
     {
       return -100;
     }
@@ -1671,9 +1666,9 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
                            (size_t) nshards * VSA_CURSOR_STRIDE * 8, stream));
     tsearch.start();
 #define VSA_PEAKS(PIECES, NT)                                                 \
-  k_selfmum_peaks<PIECES, NT><<<(unsigned int) nblocks, VSA_BLOCK, 0,         \
-                                stream>>>(                                    \
-      ix.lcp, ix.bwt, n, slmin, rawpos.as<uint32_t>(), shardcap, nshards - 1, \
+  k_selfmum_peaks<PIECES, NT, IDX><<<(unsigned int) nblocks, VSA_BLOCK, 0,    \
+                                     stream>>>(                               \
+      ix.lcp, ix.bwt, n, slmin, rawpos.as<IDX>(), shardcap, nshards - 1,      \
       cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi)
     switch (variant)
     {
@@ -1715,30 +1710,31 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   uint64_t nm = 0;
   if (needed > 0)
   {
-    if (peaks.alloc(needed * 4) || sorted.alloc(needed * 4) ||
+    if (peaks.alloc(needed * sizeof(IDX)) ||
+        sorted.alloc(needed * sizeof(IDX)) ||
         cand.alloc(needed * sizeof(vsa_match)) || keep.alloc(needed) ||
         mums.alloc(needed * sizeof(vsa_match)))
     {
       return -100;
     }
-    k_gather_u32_shards<<<nshards, VSA_BLOCK, 0, stream>>>(
-        rawpos.as<uint32_t>(), shardcap, cursor.as<unsigned long long>(),
-        doff.as<uint64_t>(), peaks.as<uint32_t>());
+    k_gather_shards<IDX><<<nshards, VSA_BLOCK, 0, stream>>>(
+        rawpos.as<IDX>(), shardcap, cursor.as<unsigned long long>(),
+        doff.as<uint64_t>(), peaks.as<IDX>());
     VSA_HIP(hipGetLastError());
     // the reference reports in suffix-array order
     size_t tb = 0;
-    VSA_HIP(rocprim::radix_sort_keys(nullptr, tb, peaks.as<uint32_t>(),
-                                     sorted.as<uint32_t>(), (size_t) needed,
+    VSA_HIP(rocprim::radix_sort_keys(nullptr, tb, peaks.as<IDX>(),
+                                     sorted.as<IDX>(), (size_t) needed,
                                      0u, bitsfor(n), stream));
     if (temp.alloc(tb))
     {
       return -100;
     }
-    VSA_HIP(rocprim::radix_sort_keys(temp.p, tb, peaks.as<uint32_t>(),
-                                     sorted.as<uint32_t>(), (size_t) needed,
+    VSA_HIP(rocprim::radix_sort_keys(temp.p, tb, peaks.as<IDX>(),
+                                     sorted.as<IDX>(), (size_t) needed,
                                      0u, bitsfor(n), stream));
     k_selfmum_emit<IDX><<<gridfor(needed), VSA_BLOCK, 0, stream>>>(
-        ix, sorted.as<uint32_t>(), needed, searchlength,
+        ix, sorted.as<IDX>(), needed, searchlength,
         index->querysepposition, cand.as<vsa_match>(), keep.as<uint8_t>());
     VSA_HIP(hipGetLastError());
     if (compact_matches(cand.as<vsa_match>(), keep.as<uint8_t>(), needed,
