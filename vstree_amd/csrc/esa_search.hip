@@ -960,7 +960,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   const bool deepok = ix.esa8 != nullptr && searchlength >= ix.D;
   tall.start();
   // MUM modes over batches of equal-length queries: anchor pass + work list
-  DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wnlist, wfirste,
+  DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wfirste,
       wfmlen, wfmdb, wfslot;
   uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
   bool firstpass = false, fromplan = false;
@@ -1063,8 +1063,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       // a plan; after the first pass every unfinished query gets one
       PlanWanted wanted{wcount.as<uint32_t>(),
                         firstpass ? 0u : searchlength + 6};
-      if (wplan.alloc(nq * sizeof(PlanRanges)) || wlist.alloc(nq * 4) ||
-          wnlist.alloc(8))
+      if (wplan.alloc(nq * sizeof(PlanRanges)) || wlist.alloc(nq * 4))
       {
         return -100;
       }
@@ -1076,20 +1075,35 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
             wcount.as<uint32_t>(), nq, wplan.as<PlanRanges>());
         VSA_HIP(hipGetLastError());
       }
-      VSA_HIP(rocprim::select(nullptr, tb,
-                              rocprim::counting_iterator<uint32_t>(0),
-                              wlist.as<uint32_t>(), wnlist.as<uint64_t>(),
-                              (size_t) nq, wanted, stream));
-      if (wtemp.alloc(tb))
       {
-        return -100;
-      }
-      VSA_HIP(rocprim::select(wtemp.p, tb,
-                              rocprim::counting_iterator<uint32_t>(0),
-                              wlist.as<uint32_t>(), wnlist.as<uint64_t>(),
-                              (size_t) nq, wanted, stream));
-      {
-        const Fetch f = {wnlist.p, 8};
+        // (queries < 2^32: the condition of this branch)
+        const uint64_t nb = blocksfor(nq), nbr = vsa_grid_blocks(nb);
+        const uint32_t threshold = wanted.threshold;
+        DevBuf bcount, boffset;
+        if (bcount.alloc((nbr + 1) * 4) || boffset.alloc((nbr + 1) * 4))
+        {
+          return -100;
+        }
+        k_wanted_count<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
+            wcount.as<uint32_t>(), nq, threshold, bcount.as<uint32_t>());
+        VSA_HIP(hipGetLastError());
+        VSA_HIP(rocprim::exclusive_scan(nullptr, tb, bcount.as<uint32_t>(),
+                                        boffset.as<uint32_t>(), (uint32_t) 0,
+                                        (size_t) (nb + 1),
+                                        rocprim::plus<uint32_t>(), stream));
+        if (wtemp.alloc(tb))
+        {
+          return -100;
+        }
+        VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, bcount.as<uint32_t>(),
+                                        boffset.as<uint32_t>(), (uint32_t) 0,
+                                        (size_t) (nb + 1),
+                                        rocprim::plus<uint32_t>(), stream));
+        k_wanted_fill<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
+            wcount.as<uint32_t>(), nq, threshold, boffset.as<uint32_t>(),
+            wlist.as<uint32_t>());
+        VSA_HIP(hipGetLastError());
+        const Fetch f = {boffset.as<uint32_t>() + nb, 4};
         if (fetchwords(stream, &f, 1, &nlist))
         {
           return -100;
