@@ -963,7 +963,37 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wfirste,
       wfmlen, wfmdb, wfslot;
   uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
-  bool firstpass = false, fromplan = false;
+  // -mum with the filter: candidates as (sort key, value) pairs, see
+  // mumfilter_packed
+  const bool keeppairs = domum && domumcand && !ordered && forcebits != 0;
+  const unsigned int lenbits =
+                         keeppairs ? forcebits : bitsfor(queries->maxlength),
+                     dbbits = bitsfor(index->n);
+  const bool packed = domum && (!domumcand || keeppairs) &&
+                      ((index->tune & 16u) == 0 || keeppairs) &&
+                      lenbits + dbbits <= 64 &&
+                      lenbits >= bitsfor(queries->maxlength) &&
+                      queries->maxlength < 0xFFFFu &&
+                      ((queries->nq + qs.seqoffset) >> 48) == 0;
+  if (keeppairs && !packed)
+  {
+    VSA_ERROR("packed candidates: %u length bits do not fit this batch "
+              "(longest query %lu, index %lu)", forcebits,
+              (unsigned long) queries->maxlength, (unsigned long) index->n);
+    return -2;
+  }
+  const uint32_t packbits = packed ? lenbits : 0;
+  // 4-byte values where query number and offset fit (not for pairs that
+  // travel to other ranks: those carry the global query number)
+  const uint32_t valbits =
+      (packed && !keeppairs && (index->tune & 32u) == 0 &&
+       ((queries->nq << lenbits) >> 32) == 0)
+          ? lenbits
+          : 0;
+  const size_t recsize = valbits != 0 ? 4 : (packed ? 8 : sizeof(vsa_match));
+  bool firstpass = false, fromplan = false, planemit = false;
+  DevBuf pcursor, pdoff, psummary, prawout, prawkeys; // see PlanEmit
+  uint64_t pcap = 0, nplan = 0;
   const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
   double anchorms = 0;
@@ -1056,6 +1086,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipGetLastError());
     size_t tb = 0;
+    // planned MUM batch on the deep tables: the search kernel reads the
+    // plans itself (k_query_search_planned) -- no scan over the queries, no
+    // work list, no read-back of its length (a workgroup size in VSA_TUNE bits
+    // 8-19, e.g. VSA_TUNE=256, selects the list form)
+    fromplan = planned && domum && deepok && qblock == 0;
     if (planned)
     {
       uint64_t nlist = 0;
@@ -1111,7 +1146,47 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       }
       if (nlist > 0)
       {
-        if (deepok)
+        // (VSA_PLAN_EMIT=0: the plan's own searches are repeated by the search
+        // kernel, as before round 2)
+        const char *noemit = getenv("VSA_PLAN_EMIT");
+        planemit = fromplan && firstpass &&
+                   !(noemit != nullptr && strcmp(noemit, "0") == 0);
+        if (planemit)
+        {
+          // room for every search A of the workgroups that share a region
+          const uint64_t nb = blocksfor(nlist),
+                         pershard = (nb + nshards - 1) / nshards;
+          pcap = pershard * VSA_BLOCK * (VSA_PLAN_ROUNDS - 1);
+          if (pcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
+              pdoff.alloc(nshards * 8) || psummary.alloc(4 * 8) ||
+              prawout.alloc(nshards * pcap * recsize) ||
+              prawkeys.alloc(nshards * pcap * 8))
+          {
+            return -100;
+          }
+          VSA_HIP(hipMemsetAsync(pcursor.p, 0,
+                                 (size_t) nshards * VSA_CURSOR_STRIDE * 8,
+                                 stream));
+          PlanEmit em;
+          em.base = dbase;
+          em.perquery = perquery;
+          em.out = prawout.as<vsa_match>();
+          em.outkey = prawkeys.as<uint64_t>();
+          em.shardcap = pcap;
+          em.shardmask = nshards - 1;
+          em.cursors = pcursor.as<unsigned long long>();
+          em.packbits = packbits;
+          em.valbits = valbits;
+          k_mum_plan<IDX, true, true>
+              <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+                  ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+                  wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
+                  wplan.as<PlanRanges>(), em);
+          k_shard_summary<<<1, 1024, 0, stream>>>(
+              pcursor.as<unsigned long long>(), nshards,
+              pdoff.as<uint64_t>(), nullptr, nullptr,
+              psummary.as<uint64_t>());
+        } else if (deepok)
         {
           k_mum_plan<IDX, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
               ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
@@ -1128,11 +1203,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       }
       plansearches = 2 * nlist;
     }
-    // planned MUM batch on the deep tables: the search kernel reads the
-    // plans itself (k_query_search_planned) -- no scan over the queries, no
-    // work list, no read-back of its length (a workgroup size in VSA_TUNE bits
-    // 8-19, e.g. VSA_TUNE=256, selects the list form)
-    fromplan = planned && domum && deepok && qblock == 0;
     if (fromplan)
     {
       tanchor.stop();
@@ -1246,34 +1316,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       std::max<uint64_t>((queries->nq * 2 / nshards) * 5 / 4 + 64, 256);
   uint64_t needed = 0, maxshard = 0;
   double searchms = 0;
-  // -mum with the filter: candidates as (sort key, value) pairs, see
-  // mumfilter_packed
-  const bool keeppairs = domum && domumcand && !ordered && forcebits != 0;
-  const unsigned int lenbits =
-                         keeppairs ? forcebits : bitsfor(queries->maxlength),
-                     dbbits = bitsfor(index->n);
-  const bool packed = domum && (!domumcand || keeppairs) &&
-                      ((index->tune & 16u) == 0 || keeppairs) &&
-                      lenbits + dbbits <= 64 &&
-                      lenbits >= bitsfor(queries->maxlength) &&
-                      queries->maxlength < 0xFFFFu &&
-                      ((queries->nq + qs.seqoffset) >> 48) == 0;
-  if (keeppairs && !packed)
-  {
-    VSA_ERROR("packed candidates: %u length bits do not fit this batch "
-              "(longest query %lu, index %lu)", forcebits,
-              (unsigned long) queries->maxlength, (unsigned long) index->n);
-    return -2;
-  }
-  const uint32_t packbits = packed ? lenbits : 0;
-  // 4-byte values where query number and offset fit (not for pairs that
-  // travel to other ranks: those carry the global query number)
-  const uint32_t valbits =
-      (packed && !keeppairs && (index->tune & 32u) == 0 &&
-       ((queries->nq << lenbits) >> 32) == 0)
-          ? lenbits
-          : 0;
-  const size_t recsize = valbits != 0 ? 4 : (packed ? 8 : sizeof(vsa_match));
   // MUM search on the deep tables, VSA_TUNE bit 6 (experiment, off by
   // default): work-items whose matched length needs the text (true matches, 3
   // in 100) go to a list and get a kernel of their own (k_query_deferred).  A
@@ -1454,16 +1496,18 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         summary.as<uint64_t>());
     VSA_HIP(hipGetLastError());
     {
-      const Fetch f[5] = {{summary.as<uint64_t>(), 8},
+      const Fetch f[6] = {{summary.as<uint64_t>(), 8},
                           {summary.as<uint64_t>() + 1, 8},
                           {summary.as<uint64_t>() + 2, 8},
                           {summary.as<uint64_t>() + 3, 8},
-                          {summary.as<uint64_t>() + 4, 8}};
-      uint64_t got[5];
-      if (fetchwords(stream, f, 5, got))
+                          {summary.as<uint64_t>() + 4, 8},
+                          {planemit ? psummary.p : summary.p, 8}};
+      uint64_t got[6];
+      if (fetchwords(stream, f, 6, got))
       {
         return -100;
       }
+      nplan = planemit ? got[5] : 0;
       needed = got[0];
       maxshard = got[1];
       nfirst = firstpass ? got[2] + (got[3] != 0 ? 1 : 0) : 0;
@@ -1482,12 +1526,34 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
               (unsigned long long) maxshard, (unsigned long long) shardcap);
     return -5;
   }
-  if (needed + nfirst > 0)
+  if (needed + nplan + nfirst > 0)
   {
-    if (out.alloc((needed + nfirst) * recsize) ||
-        keys.alloc((needed + nfirst) * 8))
+    if (out.alloc((needed + nplan + nfirst) * recsize) ||
+        keys.alloc((needed + nplan + nfirst) * 8))
     {
       return -100;
+    }
+    if (nplan > 0 && valbits != 0)
+    {
+      k_compact_shards<uint32_t><<<nshards, VSA_BLOCK, 0, stream>>>(
+          prawout.as<uint32_t>(), prawkeys.as<uint64_t>(), pcap,
+          pcursor.as<unsigned long long>(), pdoff.as<uint64_t>(),
+          out.as<uint32_t>() + needed, keys.as<uint64_t>() + needed);
+      VSA_HIP(hipGetLastError());
+    } else if (nplan > 0 && packed)
+    {
+      k_compact_shards<uint64_t><<<nshards, VSA_BLOCK, 0, stream>>>(
+          prawout.as<uint64_t>(), prawkeys.as<uint64_t>(), pcap,
+          pcursor.as<unsigned long long>(), pdoff.as<uint64_t>(),
+          out.as<uint64_t>() + needed, keys.as<uint64_t>() + needed);
+      VSA_HIP(hipGetLastError());
+    } else if (nplan > 0)
+    {
+      k_compact_shards<vsa_match><<<nshards, VSA_BLOCK, 0, stream>>>(
+          prawout.as<vsa_match>(), prawkeys.as<uint64_t>(), pcap,
+          pcursor.as<unsigned long long>(), pdoff.as<uint64_t>(),
+          out.as<vsa_match>() + needed, keys.as<uint64_t>() + needed);
+      VSA_HIP(hipGetLastError());
     }
     if (needed > 0 && valbits != 0)
     {
@@ -1516,11 +1582,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       k_append_first<<<gridfor(queries->nq), VSA_BLOCK, 0, stream>>>(
           wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
           wfslot.as<uint32_t>(), queries->nq, perquery, dbase, qs.seqoffset,
-          needed,
+          needed + nplan,
           out.as<vsa_match>(), keys.as<uint64_t>(), packbits, valbits);
       VSA_HIP(hipGetLastError());
     }
-    needed += nfirst;
+    needed += nplan + nfirst;
   }
   res->stats.candidates = domum ? needed : 0;
   if (keeppairs)
