@@ -765,8 +765,11 @@ int mumuniqueinquery(DevBuf &cand, uint64_t ncand, hipStream_t stream,
 // querystart (k_query_search with packbits).  One sort of the pairs, the
 // filter on the keys, and the surviving pairs become the records: the
 // candidates never exist as 32-byte records.
-template <typename VAL = uint64_t>
-int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
+// keys_in / vals_in: anything rocPRIM can read (pointers, or iterators over
+// rows of pairs as they come out of the exchange: no copy into two arrays)
+template <typename VAL = uint64_t, typename KeyIn = const uint64_t *,
+          typename ValIn = const VAL *>
+int mumfilter_packed(KeyIn keys_in, ValIn vals_in, uint64_t ncand,
                      unsigned int lenbits, unsigned int dbbits,
                      hipStream_t stream, DevBuf &mums, uint64_t *nmums,
                      uint64_t *sumlength, uint64_t carry = 0,
@@ -802,14 +805,14 @@ int mumfilter_packed(DevBuf &keys, DevBuf &vals, uint64_t ncand,
     VSA_HIP(hipMemsetAsync(dcount.p, 0, 24, stream));
     tb = 0;
     VSA_HIP(rocprim::radix_sort_pairs(
-        nullptr, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<VAL>(),
+        nullptr, tb, keys_in, k2.as<uint64_t>(), vals_in,
         v2.as<VAL>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
     if (temp.alloc(tb))
     {
       return -100;
     }
     VSA_HIP(rocprim::radix_sort_pairs(
-        temp.p, tb, keys.as<uint64_t>(), k2.as<uint64_t>(), vals.as<VAL>(),
+        temp.p, tb, keys_in, k2.as<uint64_t>(), vals_in,
         v2.as<VAL>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
     // running maximum of the right ends, which are a function of the keys
     auto ends = rocprim::make_transform_iterator(k2.as<uint64_t>(),
@@ -1604,7 +1607,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     uint64_t nm = 0;
     if (valbits != 0)
     {
-      if (mumfilter_packed<uint32_t>(keys, out, needed, lenbits, dbbits,
+      if (mumfilter_packed<uint32_t>(keys.as<const uint64_t>(),
+                                     out.as<const uint32_t>(), needed, lenbits, dbbits,
                                      stream, mums, &nm, &mumsum, 0, valbits,
                                      qs.seqoffset))
       {
@@ -1612,7 +1616,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       }
     } else if (packed)
     {
-      if (mumfilter_packed(keys, out, needed, lenbits, dbbits, stream, mums,
+      if (mumfilter_packed(keys.as<const uint64_t>(),
+                           out.as<const uint64_t>(), needed, lenbits, dbbits, stream, mums,
                            &nm, &mumsum))
       {
         return -100;
@@ -2414,24 +2419,25 @@ k_partition_count(const PartInput in, uint64_t n,
 }
 
 // per part: where it starts in the output and its largest right end
-__global__ void __launch_bounds__(VSA_BLOCK)
+// (1024 lanes: one workgroup per part walks all the blocks' maxima)
+__global__ void __launch_bounds__(1024)
 k_partition_summary(const uint64_t *__restrict__ offsets,
                     const unsigned long long *__restrict__ blocktop,
                     uint32_t nparts, uint64_t nblocks,
                     uint64_t *__restrict__ partstart,
                     unsigned long long *__restrict__ parttop)
 {
-  __shared__ unsigned long long red[VSA_BLOCK];
+  __shared__ unsigned long long red[1024];
   const uint32_t p = vsa_bid();
   unsigned long long best = 0;
-  for (uint64_t b = threadIdx.x; b < nblocks; b += VSA_BLOCK)
+  for (uint64_t b = threadIdx.x; b < nblocks; b += 1024)
   {
     const unsigned long long v = blocktop[(uint64_t) p * nblocks + b];
     best = v > best ? v : best;
   }
   red[threadIdx.x] = best;
   __syncthreads();
-  for (int d = VSA_BLOCK / 2; d > 0; d >>= 1)
+  for (int d = 512; d > 0; d >>= 1)
   {
     if ((int) threadIdx.x < d && red[threadIdx.x + d] > red[threadIdx.x])
     {
@@ -2559,7 +2565,7 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   VSA_HIP(rocprim::exclusive_scan(temp.p, tb, widen, offsets.as<uint64_t>(),
                                   (uint64_t) 0, (size_t) (cells + 1),
                                   rocprim::plus<uint64_t>(), stream));
-  k_partition_summary<<<nparts, VSA_BLOCK, 0, stream>>>(
+  k_partition_summary<<<nparts, 1024, 0, stream>>>(
       offsets.as<uint64_t>(), top.as<unsigned long long>(), nparts, nblocks,
       summary.as<uint64_t>(),
       summary.as<unsigned long long>() + VSA_PART_MAX + 1);
@@ -2786,19 +2792,16 @@ extern "C" int vsa_mumuniqueinquery_range(void *device_candidates,
                          carry_dbright, result);
 }
 
-// rows of (key, value) -> two arrays
-__global__ void __launch_bounds__(VSA_BLOCK)
-k_split_rows(const uint4 *__restrict__ rows, uint64_t n,
-             uint64_t *__restrict__ key, uint64_t *__restrict__ val)
+// word 0 / word 1 of row i of (key, value) pairs
+struct RowWord
 {
-  const uint64_t t = vsa_bid() * VSA_BLOCK + threadIdx.x;
-  if (t < n)
+  const uint64_t *rows;
+  uint32_t word;
+  __device__ uint64_t operator()(size_t i) const
   {
-    const uint4 r = rows[t];
-    key[t] = ((uint64_t) r.y << 32) | r.x;
-    val[t] = ((uint64_t) r.w << 32) | r.z;
+    return rows[2 * i + word];
   }
-}
+};
 
 // pairs -> records, in place order (vsa_result_fetch of a packed result)
 __global__ void __launch_bounds__(VSA_BLOCK)
@@ -2853,26 +2856,22 @@ extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
   hipStream_t stream = nullptr; // default stream: no index handle here
   vsa_dev_set_stream(stream);
   Timer tall(stream);
-  DevBuf keys, vals, mums;
+  DevBuf mums;
   uint64_t nm = 0, sum = 0;
   tall.start();
   int rc = 0;
   if (nrows > 0)
   {
-    if (keys.alloc(nrows * 8) || vals.alloc(nrows * 8))
-    {
-      rc = -100;
-    } else
-    {
-      k_split_rows<<<gridfor(nrows), VSA_BLOCK, 0, stream>>>(
-          reinterpret_cast<const uint4 *>(device_rows), nrows,
-          keys.as<uint64_t>(), vals.as<uint64_t>());
-      rc = hipGetLastError() == hipSuccess
-               ? mumfilter_packed(keys, vals, nrows, lengthbits,
-                                  bitsfor(totallength), stream, mums, &nm,
-                                  &sum, carry_dbright)
-               : -100;
-    }
+    // the sort reads the rows as they lie (the first pass of the radix sort
+    // takes iterators): no split into two arrays
+    const uint64_t *rows = reinterpret_cast<const uint64_t *>(device_rows);
+    auto rowkeys = rocprim::make_transform_iterator(
+        rocprim::counting_iterator<size_t>(0), RowWord{rows, 0});
+    auto rowvals = rocprim::make_transform_iterator(
+        rocprim::counting_iterator<size_t>(0), RowWord{rows, 1});
+    rc = mumfilter_packed<uint64_t>(rowkeys, rowvals, nrows, lengthbits,
+                                    bitsfor(totallength), stream, mums, &nm,
+                                    &sum, carry_dbright);
   }
   tall.stop();
   if (rc != 0)
