@@ -122,9 +122,16 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     meta = torch.as_tensor(np.concatenate([np.asarray(send, np.int64),
                                            np.asarray(maxright, np.int64)]),
                            device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    table = torch.stack(metas).cpu().numpy()        # [sender, 2*world]
+    try:
+        # one tensor in, one out: no list of outputs to allocate and stack
+        gathered = torch.empty(world * meta.numel(), dtype=meta.dtype,
+                               device=device)
+        dist.all_gather_into_tensor(gathered, meta)
+        table = gathered.reshape(world, -1).cpu().numpy()   # [sender, 2*world]
+    except (RuntimeError, NotImplementedError, AttributeError):
+        metas = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta)
+        table = torch.stack(metas).cpu().numpy()
     sends, tops = table[:, :world], table[:, world:]
     recv = [int(x) for x in sends[:, me]]
     # largest right end among ALL candidates of the ranges below mine
