@@ -33,6 +33,8 @@ M, L = 100, 20
 def world(V):
     if N == 0:
         pytest.skip("VSA_WIDE_BP=0")
+    import gc
+    gc.collect()            # indexes of earlier modules release their HBM
     V.lib.vsa_device_trim(0)
     dg = V.device_malloc(N + 64)
     V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, N, dg, 0))
