@@ -947,3 +947,29 @@ def test_inconsistent_tables_are_refused_on_upload(V):
         with pytest.raises(V.VsaError) as e:
             upload(**kw)
         assert e.value.code == -2 and what in e.value.message, kw
+
+
+@pytest.mark.parametrize("name,value", [("VSA_PLAN_EMIT", "0"),
+                                        ("VSA_K2_TWOPHASE", "1"),
+                                        ("VSA_TANDEM_ISA", "1")])
+def test_round2_experiment_switches_give_the_same_lists(V, name, value,
+                                                        monkeypatch):
+    """the work plan without its own answers, the two-phase search kernel and
+    the tandem kernel on the inverse suffix array (esa_search.hip,
+    selfmatch_search.inc): measured alternatives that stay in the library"""
+    monkeypatch.setenv(name, value)
+    if name == "VSA_TANDEM_ISA":
+        for case, key in (("at1mb", "tandem40"), ("at1mb", "tandem5"),
+                          ("grumbach", "tandem3"), ("largepat", "tandem8")):
+            idx, _ = H.load_case(case)
+            got = H.repeats_as_ref(idx, V.findtandems(
+                gpu_index(V, case), int(key[len("tandem"):])).fetch())
+            assert np.array_equal(got, H.expected(case, key)), (case, key)
+        return
+    idx, q = H.load_case("c1")
+    gi, gq = gpu_index(V, "c1"), gpu_queries(V, q)
+    for key, kw in (("mum20", dict(mum=True)),
+                    ("mumcand20", dict(mum=True, cand=True))):
+        got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
+                                                       **kw).fetch())
+        assert np.array_equal(got, H.expected("c1", key)), (name, key)
