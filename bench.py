@@ -82,6 +82,14 @@ def parse():
     # one rank, but through the N > 1 code path with the real backend (RCCL):
     # process group, all-to-all / all-gather / all-reduce on device tensors
     ap.add_argument("--force-distributed", action="store_true")
+    # N > 1: `torch` = one process per GPU (torch.distributed, RCCL), what the
+    # driver launches; `c` = ONE process that drives all GPUs through
+    # libvstree_amd_multi.so (vsa_multi_findmatches: a host thread per GPU,
+    # peer copies for the -mum exchange, ncclAllReduce of the counters) -- the
+    # path the drop-in binary takes (VMATCH_GPUS=N)
+    ap.add_argument("--path", choices=("torch", "c"), default="torch")
+    # --path c on a box with one GPU: N replicas of the index on device 0
+    ap.add_argument("--replicas-on-one-gpu", action="store_true")
     return ap.parse_args()
 
 
@@ -282,6 +290,44 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
         shutil.rmtree(wd, ignore_errors=True)
 
 
+def launch_ranks(a, jsonfd):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks
+    through torch.distributed.run (what the driver's own command line does),
+    relay rank 0's JSON line.  device_count() does not initialise the GPU."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if not a.rehearse_on_one_gpu and have < a.gpus:
+        log("bench.py: --gpus %d, but this node shows %d GPU(s)"
+            % (a.gpus, have))
+        sys.exit(2)
+    if a.rehearse_on_one_gpu and have < 1:
+        log("bench.py: no GPU")
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for l in p.stdout.decode().splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+    if p.returncode != 0 or line is None:
+        log("bench.py: the %d ranks ended with code %d%s"
+            % (a.gpus, p.returncode, "" if line else " and printed no line"))
+        sys.exit(p.returncode or 3)
+    d = json.loads(line)
+    if d.get("n_gpus") != a.gpus:
+        log("bench.py: asked for %d GPUs, the ranks report %r"
+            % (a.gpus, d.get("n_gpus")))
+        sys.exit(3)
+    os.write(jsonfd, (line + "\n").encode())
+
+
 def selfmum_text(V, n):
     """db half + separator + a copy with one substitution every 97 bp: every
     suffix pair is an lcp peak (the dense case of scripts/selfmum_probe.py)"""
@@ -302,12 +348,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            log("bench.py: --gpus %d needs torch.distributed.run; running the "
-                "single-process case" % a.gpus)
-        a.gpus = world
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.path == "torch":
+        # started directly: become the launcher of N ranks (one per GPU) before
+        # anything touches a GPU, hand their one JSON line on, leave with
+        # their exit code
+        return launch_ranks(a, jsonfd)
+    if world != a.gpus and a.path == "torch":
+        log("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a line "
+            "for another number of GPUs than asked for" % (a.gpus, world))
+        sys.exit(2)
     dev = 0 if a.rehearse_on_one_gpu else local_rank
+    if a.path == "c":
+        return c_path_mode(a, jsonfd)
 
     torch = dist = S = None
     distributed = world > 1 or a.force_distributed

@@ -559,6 +559,10 @@ int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);
    64-byte sector per read that misses the caches. */
 int vsa_measure_random_read(uint64_t bytes, int inflight, int device,
                             double *greads);
+/* the same reads over a table of a live index, where it lies in device
+   memory: 0 slot16 (16-byte reads), 1 esa8, 2 tis2, 3 suf */
+int vsa_measure_table_read(const vsa_index *ix, int table, int inflight,
+                           double *greads);
 
 /* ---- host match sink: from match records to vmatch's output lines ------ */
 

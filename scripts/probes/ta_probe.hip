@@ -50,7 +50,7 @@ k_rr(const T *__restrict__ buf, uint64_t nelem, uint32_t per,
   {
     return;
   }
-  uint64_t x = t * 0x9E3779B97F4A7C15ull + 1, acc = 0;
+  uint64_t x = t * (uint64_t) per * 0x9E3779B97F4A7C15ull + 1 /* disjoint sequences: see api.hip */, acc = 0;
   for (uint32_t i = 0; i < per; i += INFLIGHT)
   {
     T v[INFLIGHT], w[INFLIGHT];

@@ -167,6 +167,7 @@ def _load():
         "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
         "vsa_findmaximaluniquematches_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_measure_random_read": (I, [U64, I, I, C.POINTER(C.c_double)]),
+        "vsa_measure_table_read": (I, [V, I, I, C.POINTER(C.c_double)]),
         "vsa_sink_open": (I, [C.POINTER(SinkParams), PP]),
         "vsa_sink_close": (None, [V]),
         "vsa_sink_format": (C.c_int64, [V, V, U64, V, U64]),

@@ -1037,7 +1037,12 @@ k_random_read(const uint64_t *__restrict__ buf, uint64_t nwords,
               uint64_t perthread, unsigned long long *__restrict__ sink)
 {
   const uint64_t t = vsa_bid() * 256 + threadIdx.x;
-  uint64_t x = t * 0x9E3779B97F4A7C15ull + 1, acc = 0;
+  // (x = (t * perthread + i + 1) * golden: every (thread, step) has a value
+  // of its own.  Until round 3 the sequence was (t + i) * golden -- thread t's
+  // step i read what thread t + 1 had read one step earlier, 92 % of the
+  // "random" reads hit L2, and the 76 G reads/s this probe reported for two
+  // rounds was not the rate of HBM.)
+  uint64_t x = t * perthread * 0x9E3779B97F4A7C15ull + 1, acc = 0;
   for (uint64_t i = 0; i < perthread; i += INFLIGHT)
   {
     uint64_t v[INFLIGHT];
@@ -1110,6 +1115,132 @@ extern "C" int vsa_measure_random_read(uint64_t bytes, int inflight,
   (void) hipEventDestroy(a);
   (void) hipEventDestroy(b);
   (void) hipFree(buf);
+  (void) hipFree(sink);
+  return 0;
+}
+
+// the same probe on a table of a live index, where the driver happened to
+// place it: 0 slot16 (16-byte reads of whole slots), 1 esa8 (8-byte), 2 tis2,
+// 3 suf
+template <typename T, int INFLIGHT>
+__global__ void __launch_bounds__(256)
+k_table_read(const T *__restrict__ buf, uint64_t nitems, uint64_t perthread,
+             unsigned long long *__restrict__ sink)
+{
+  const uint64_t t = vsa_bid() * 256 + threadIdx.x;
+  uint64_t x = t * perthread * 0x9E3779B97F4A7C15ull + 1, acc = 0;
+  for (uint64_t i = 0; i < perthread; i += INFLIGHT)
+  {
+    T v[INFLIGHT];
+#pragma unroll
+    for (int k = 0; k < INFLIGHT; k++)
+    {
+      x += 0x9E3779B97F4A7C15ull;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      v[k] = buf[z % nitems];
+    }
+#pragma unroll
+    for (int k = 0; k < INFLIGHT; k++)
+    {
+      if constexpr (sizeof(T) == 16)
+      {
+        acc += (uint64_t) v[k].x + v[k].y + v[k].z + v[k].w;
+      } else
+      {
+        acc += (uint64_t) v[k];
+      }
+    }
+  }
+  if (acc == 0x1234567ull)
+  {
+    atomicAdd(sink, 1ull);
+  }
+}
+
+extern "C" int vsa_measure_table_read(const vsa_index *ix, int table,
+                                      int inflight, double *greads)
+{
+  if (ix == nullptr || greads == nullptr || vsa_set_device(ix->device) != 0)
+  {
+    return -100;
+  }
+  const void *buf = nullptr;
+  uint64_t nitems = 0;
+  int width = 8;
+  if (table == 0 && ix->slot16 != nullptr)
+  {
+    buf = ix->slot16;
+    nitems = (1ull << (2 * ix->D)) * (ix->slotwords / 2);
+    width = 16;
+  } else if (table == 1 && ix->esa8 != nullptr)
+  {
+    buf = ix->esa8;
+    nitems = ix->n + 1;
+  } else if (table == 2 && ix->tis2 != nullptr)
+  {
+    buf = ix->tis2;
+    nitems = (ix->n / 4) / 8;
+  } else if (table == 3)
+  {
+    buf = ix->suf;
+    nitems = (ix->n + 1) * ix->isize / 8;
+  } else if (table == 4 && ix->slot16 != nullptr) // slot16, 8-byte reads
+  {
+    buf = ix->slot16;
+    nitems = (1ull << (2 * ix->D)) * ix->slotwords;
+  } else if (table == 5 && ix->esa8 != nullptr) // esa8, 16-byte reads
+  {
+    buf = ix->esa8;
+    nitems = (ix->n + 1) / 2;
+    width = 16;
+  } else
+  {
+    VSA_ERROR("vsa_measure_table_read: the index has no table %d", table);
+    return -2;
+  }
+  unsigned long long *sink = nullptr;
+  VSA_HIP(vsa_hip_malloc((void **) &sink, 8));
+  VSA_HIP(hipMemset(sink, 0, 8));
+  const uint64_t threads = 256ull * 256 * 32, perthread = 64;
+  hipEvent_t a, b;
+  VSA_HIP(hipEventCreate(&a));
+  VSA_HIP(hipEventCreate(&b));
+  const int reps = 3;
+  for (int r = 0; r <= reps; r++)
+  {
+    if (r == 1)
+    {
+      VSA_HIP(hipEventRecord(a, 0));
+    }
+    const unsigned int grid = (unsigned int) (threads / 256);
+    if (width == 16 && inflight >= 4)
+    {
+      k_table_read<uint4, 4><<<grid, 256>>>((const uint4 *) buf, nitems,
+                                             perthread, sink);
+    } else if (width == 16)
+    {
+      k_table_read<uint4, 1><<<grid, 256>>>((const uint4 *) buf, nitems,
+                                             perthread, sink);
+    } else if (inflight >= 4)
+    {
+      k_table_read<uint64_t, 4><<<grid, 256>>>((const uint64_t *) buf, nitems,
+                                                perthread, sink);
+    } else
+    {
+      k_table_read<uint64_t, 1><<<grid, 256>>>((const uint64_t *) buf, nitems,
+                                                perthread, sink);
+    }
+  }
+  VSA_HIP(hipEventRecord(b, 0));
+  VSA_HIP(hipEventSynchronize(b));
+  float ms = 0;
+  VSA_HIP(hipEventElapsedTime(&ms, a, b));
+  *greads = (double) threads * perthread * reps / ((double) ms * 1e-3) / 1e9;
+  (void) hipEventDestroy(a);
+  (void) hipEventDestroy(b);
   (void) hipFree(sink);
   return 0;
 }

@@ -34,6 +34,9 @@
 #include "vsa_internal.hpp"
 #include <type_traits>
 
+// VSA_TUNE bit 20 (round 3, see esa_search.hip)
+#define VSA_TUNE_OLDBUCKET (1u << 20) // small buckets by three loads from esa8
+
 #define VSA_ISSPECIAL(c) ((c) >= (uint8_t) VSA_WILDCARD) // chardef.h:37
 
 __device__ __forceinline__ uint64_t vsa_load8(const uint8_t *p)
@@ -426,10 +429,10 @@ __device__ __forceinline__ void vsa_pq_stage(const DevQueries &qs, uint64_t q0,
 }
 
 // vsa_extend_packed for a query that is in registers already
-template <int CHUNKS, typename IDX>
+template <int CHUNKS, typename IDX, typename QT>
 __device__ __forceinline__ bool
 vsa_extend_packed_pq(const DevIndex<IDX> &ix, uint64_t sufstart,
-                     const PackedQuery &pq, uint32_t pqoff,
+                     const QT &pq, uint32_t pqoff,
                      uint32_t querylen, uint32_t &lcplen)
 {
   // the query suffix at offset pqoff of the packed query, querylen symbols
@@ -846,11 +849,11 @@ struct DeepFront
   int state;                     // VSA_LOC_NONE / FOUND (= go on) / SLOW
 };
 
-template <bool PQ = false, typename IDX = uint32_t>
+template <bool PQ = false, typename IDX = uint32_t, typename QT = PackedQuery>
 __device__ __forceinline__ void
 vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
                uint32_t querylen, DeepFront &f,
-               const PackedQuery *pq = nullptr, uint32_t pqoff = 0)
+               const QT *pq = nullptr, uint32_t pqoff = 0)
 {
   const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
@@ -942,14 +945,49 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
   }
 }
 
+// The one suffix that ties with the query on all D + limit symbols the keys
+// cover, at sstart: how far does the match go?  maxlcp: in, the symbols known
+// to match; out, the matched length.  On the 2-bit text where there is one
+// (two pieces of 60 symbols per round trip when the caller expects long
+// matches); lanes whose comparison met a special symbol of the text repeat it
+// on the bytes.  PQ: the query is *pq (symbols from pqoff on), `query` its
+// bytes for the fallback.
+template <int AHEAD, bool PQ, typename IDX, typename QT>
+__device__ __forceinline__ void
+vsa_extend_tie(const DevIndex<IDX> &ix, uint64_t sstart, const uint8_t *query,
+               uint32_t querylen, uint32_t &maxlcp, const QT *pq,
+               uint32_t pqoff)
+{
+  uint32_t lcplen = maxlcp;
+  bool done = false;
+  if (ix.tis2 != nullptr)
+  {
+    if constexpr (PQ)
+    {
+      done = vsa_extend_packed_pq<(AHEAD > 1 ? 2 : 1)>(ix, sstart, *pq, pqoff,
+                                                       querylen, lcplen);
+    } else
+    {
+      done = vsa_extend_packed<(AHEAD > 1 ? 2 : 1)>(ix, sstart, query,
+                                                    querylen, lcplen);
+    }
+  }
+  if (!done)
+  {
+    lcplen = maxlcp;
+    (void) vsa_compare32<IDX, AHEAD>(ix, sstart, query, querylen, lcplen);
+  }
+  maxlcp = lcplen;
+}
+
 // the deep locate from a front that is at hand (all lanes, see below)
 template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
-          typename IDX = uint32_t>
+          typename IDX = uint32_t, typename QT = PackedQuery>
 __device__ __forceinline__ int
 vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
                      const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
                      uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
-                     uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
+                     uint32_t qleft = 0x100u, const QT *pq = nullptr,
                      uint32_t pqoff = 0)
 {
   // PQ: the whole query is in *pq (vsa_pq_stage / vsa_pq_load) and the
@@ -997,9 +1035,26 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
     e[0] = first;
     e[1] = second;
     e[2] = third;
+  } else if (small && ix.slot16 != nullptr && (ix.tune & VSA_TUNE_OLDBUCKET) == 0)
+  {
+    // the first entry came with the bounds: entries 1, 2 in one load, and 3, 4
+    // in a second one for the buckets that have them (a divergent load costs
+    // its CU's address unit about a cycle per lane whatever its width, and a
+    // bucket of two -- the usual case here -- needs one instead of three)
+    // (esa8 has eight entries of slack behind index n)
+    const uint64_t *p = ix.esa8 + (uint64_t) dl + 1;
+    const vsa_u128 e12 = vsa_load16(p);
+    e[0] = first;
+    e[1] = e12.lo;
+    e[2] = e12.hi;
+    if (cnt > 2)
+    {
+      const vsa_u128 e34 = vsa_load16(p + 2);
+      e[3] = e34.lo;
+      e[4] = e34.hi;
+    }
   } else if (small)
   {
-    // esa8 has eight entries of slack behind index n
     const uint64_t *p = ix.esa8 + (uint64_t) dl;
     const vsa_u128 e01 = vsa_load16(p), e23 = vsa_load16(p + 2);
     e[0] = e01.lo;
@@ -1180,36 +1235,19 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
   }
   if (extend)
   {
-    uint32_t lcplen = maxlcp;
-    // on the 2-bit text where there is one (two pieces of 60 symbols per
-    // round trip when the caller expects long matches); lanes whose
-    // comparison met a special symbol of the text repeat it on the bytes
-    bool done = false;
-    const uint64_t sstart = vsa_entrystart(ix, esucc, (uint64_t) dl + lo);
-    if (ix.tis2 != nullptr)
-    {
-      done = PQ ? vsa_extend_packed_pq<(AHEAD > 1 ? 2 : 1)>(
-                      ix, sstart, *pq, pqoff, querylen, lcplen)
-                : vsa_extend_packed<(AHEAD > 1 ? 2 : 1)>(
-                      ix, sstart, query, querylen, lcplen);
-    }
-    if (!done)
-    {
-      lcplen = maxlcp;
-      (void) vsa_compare32<IDX, AHEAD>(ix, sstart, query, querylen, lcplen);
-    }
-    maxlcp = lcplen;
+    vsa_extend_tie<AHEAD, PQ>(ix, vsa_entrystart(ix, esucc, (uint64_t) dl + lo),
+                              query, querylen, maxlcp, pq, pqoff);
   }
   return state;
 }
 
 template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
-          typename IDX = uint32_t>
+          typename IDX = uint32_t, typename QT = PackedQuery>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
                 uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
-                uint32_t qleft = 0x100u, const PackedQuery *pq = nullptr,
+                uint32_t qleft = 0x100u, const QT *pq = nullptr,
                 uint32_t pqoff = 0)
 {
   DeepFront f;

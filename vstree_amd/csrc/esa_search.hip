@@ -37,6 +37,7 @@
 //                   (instead of pairs)
 //            bit 5  8-byte values in the pairs (instead of 4-byte ones)
 //            bits 8..19  workgroup size of K2 (64, 128, 256, 512)
+//            bit 20  small deep buckets by three loads from esa8 (round 2)
 //   VSA_NO_ESA8=1, VSA_DEEP_PREFIX=D   the keyed search array off / its depth
 #include <cstring>
 #include <algorithm>
@@ -1205,6 +1206,32 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         VSA_HIP(hipGetLastError());
       }
       plansearches = 2 * nlist;
+      if (getenv("VSA_DEBUG_PLANHIST") != nullptr)
+      {
+        // how the work-items are spread over the planned reads (stderr)
+        std::vector<uint32_t> h(nq);
+        VSA_HIP(hipMemcpyAsync(h.data(), wcount.p, nq * 4,
+                               hipMemcpyDeviceToHost, stream));
+        VSA_HIP(hipStreamSynchronize(stream));
+        uint64_t hist[12] = {0}, total = 0, reads = 0;
+        for (uint64_t q = 0; q < nq; q++)
+        {
+          if (h[q] != 0)
+          {
+            hist[std::min<uint32_t>(h[q] / 8, 11)]++;
+            total += h[q];
+            reads++;
+          }
+        }
+        fprintf(stderr, "plan: %llu reads, %llu work-items;",
+                (unsigned long long) reads, (unsigned long long) total);
+        for (int b = 0; b < 12; b++)
+        {
+          fprintf(stderr, " %d-%d:%llu", 8 * b, 8 * b + 7,
+                  (unsigned long long) hist[b]);
+        }
+        fprintf(stderr, "\n");
+      }
     }
     if (fromplan)
     {
@@ -2029,6 +2056,39 @@ int vsa_index_make_esa8(vsa_index *ix)
   const char *tune = getenv("VSA_TUNE");
   ix->tune = tune != nullptr ? (uint32_t) atoi(tune) : 0;
   const uint64_t count = ix->n + 1, ncodes = 1ull << (2 * D);
+  // The slot table is the one every search starts in, at a random place: it is
+  // allocated FIRST, with the temporaries of the builder handed back to the
+  // driver.  Placed last, between what the builder had left, the 68.7 GB of a
+  // 3 Gbp index were mapped in small pages and a random read of it cost a read
+  // of the page table on top: 38 G reads/s against 77 G for every other table
+  // (scripts/table_read_probe.py, profiles/r03/table_read_probe.txt).
+  // (VSA_SLOT_ALLOC_LAST=1: the old order)
+  const char *slotenv = getenv("VSA_SLOT");
+  int slotbytes = slotenv != nullptr ? atoi(slotenv) : 16;
+  if (slotbytes != 0 && slotbytes != 16 && slotbytes != 32)
+  {
+    slotbytes = 16;
+  }
+  if (wide && slotbytes == 0)
+  {
+    slotbytes = 16; // wide tables have the fused form only
+  }
+  {
+    const char *last = getenv("VSA_SLOT_ALLOC_LAST");
+    if (slotbytes != 0 && !(last != nullptr && strcmp(last, "1") == 0))
+    {
+      VSA_HIP(hipStreamSynchronize(ix->stream));
+      vsa_dev_trim();
+      if (vsa_hip_malloc((void **) &ix->slot16,
+                         (uint64_t) (slotbytes / 8) * ncodes * 8 + 32) !=
+          hipSuccess)
+      {
+        (void) hipGetLastError();
+        ix->slot16 = nullptr; // (tried again below, smaller if need be)
+      }
+    }
+  }
+  const int slotbytesfirst = slotbytes;
   VSA_HIP(vsa_hip_malloc((void **) &ix->bck2, 2 * ncodes * ix->isize + 16));
   VSA_HIP(vsa_hip_malloc((void **) &ix->esa8, count * 8 + 64));
   ix->device_bytes += count * 8 + 2 * ncodes * ix->isize;
@@ -2090,24 +2150,20 @@ int vsa_index_make_esa8(vsa_index *ix)
   // second 16-byte load of the same sector is a request of its own and the
   // kernel is bound by requests in flight, profiles/r02/slot32_ab.txt);
   // VSA_SLOT=0 keeps bck2.  A wide form is dropped when memory is short.
-  const char *slotenv = getenv("VSA_SLOT");
-  int slotbytes = slotenv != nullptr ? atoi(slotenv) : 16;
-  if (slotbytes != 0 && slotbytes != 16 && slotbytes != 32)
-  {
-    slotbytes = 16;
-  }
-  if (wide && slotbytes == 0)
-  {
-    slotbytes = 16; // wide tables have the fused form only
-  }
   unsigned int *dtoobig = nullptr, htoobig = 0;
   VSA_HIP(vsa_hip_malloc((void **) &dtoobig, 4));
   VSA_HIP(hipMemsetAsync(dtoobig, 0, 4, ix->stream));
   for (; slotbytes >= 16; slotbytes -= 16)
   {
     const uint32_t words = (uint32_t) slotbytes / 8;
-    if (vsa_hip_malloc((void **) &ix->slot16, words * ncodes * 8 + 32) !=
-        hipSuccess)
+    if (ix->slot16 != nullptr && slotbytes != slotbytesfirst)
+    {
+      (void) hipFree(ix->slot16); // (cannot happen: it was there in time)
+      ix->slot16 = nullptr;
+    }
+    if (ix->slot16 == nullptr &&
+        vsa_hip_malloc((void **) &ix->slot16, words * ncodes * 8 + 32) !=
+            hipSuccess)
     {
       (void) hipGetLastError();
       ix->slot16 = nullptr;
