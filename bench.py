@@ -168,15 +168,22 @@ def write_fasta(path, header, symbols, width=1 << 20):
 
 
 def write_queries(path, qsym, m, first, count):
+    """count reads as FASTA, one line each: '>q' + 9 digits (the global
+    number), the symbols.  Built as one byte matrix: a Python loop over 10 M
+    reads took longer than the reference needs to match them."""
     letters = np.frombuffer(b"acgt", np.uint8)
-    rows = letters[qsym[first * m:(first + count) * m]].reshape(count, m)
+    rows = np.empty((count, 12 + m + 1), np.uint8)
+    rows[:, 0] = ord(">")
+    rows[:, 1] = ord("q")
+    ids = np.arange(first, first + count, dtype=np.int64)
+    for k in range(9):
+        rows[:, 10 - k] = (ids // 10 ** k) % 10 + 48
+    rows[:, 11] = 10
+    rows[:, 12:12 + m] = letters[qsym[first * m:(first + count) * m]
+                                 ].reshape(count, m)
+    rows[:, 12 + m] = 10
     with open(path, "wb") as f:
-        out = []
-        for i in range(count):
-            out.append(b">q%d\n" % (first + i))
-            out.append(rows[i].tobytes())
-            out.append(b"\n")
-        f.write(b"".join(out))
+        f.write(rows.tobytes())
 
 
 def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
@@ -208,6 +215,17 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
         write_queries(wd + "/q1.fna", qsym, m, 0, ns1)
         for p in range(ncores):
             write_queries(wd + "/qp%d.fna" % p, qsym, m, p * per, per)
+        # P = the physical cores of the host (lscpu), each process
+        # 1/P of the sample -- here the whole batch that is at hand
+        pphys, lscpu = physical_cores()
+        pphys = min(pphys or 0, len(os.sched_getaffinity(0)))
+        perphys = min(125000, (len(qsym) // m) // pphys) if pphys else 0
+        if pphys > ncores and perphys >= 10000:
+            for p in range(pphys):
+                write_queries(wd + "/qf%d.fna" % p, qsym, m, p * perphys,
+                              perphys)
+        else:
+            pphys = 0
         env = dict(os.environ, VMATCHSHOWTIMESPACE="on")
         args = [H.VMATCH_REF, "-mum", "-l", str(L), "-q"]
 
@@ -234,6 +252,17 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
         log("reference vmatch: index files %.0f s, 1 core %.1f s (%d queries),"
             " %d cores %.1f s (%d queries)" % (t_index, t1, ns1, ncores, tp,
                                                nsp))
+        allcores = None
+        if pphys:
+            tf, cf = run(["qf%d.fna" % p for p in range(pphys)])
+            log("reference vmatch on all %d physical cores: %.1f s (%d "
+                "queries)" % (pphys, tf, pphys * perphys))
+            allcores = {
+                "value": pphys * perphys / tf, "unit": "queries/s",
+                "cores": pphys, "kind": "reference",
+                "sample": "%d processes x %d queries (%s), wall of the "
+                          "slowest = %.1f s; %d MUMs"
+                          % (pphys, perphys, lscpu, tf, sum(cf))}
         # the drop-in binary (reference vmatch + integration/vmengine_shim.c)
         # on the same files: whole process, incl. mapping the index, its
         # upload to HBM, the derived tables, FASTA parsing and printing
@@ -285,6 +314,7 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
                 "kind": "reference",
                 "sample": "%d queries, one process, %.1f s, %d MUMs"
                           % (ns1, t1, c1[0])},
+            "reference_physical_cores": allcores,
             "mums_1core_sample": c1[0], "dropin_end_to_end": dropin}
     finally:
         shutil.rmtree(wd, ignore_errors=True)
@@ -326,6 +356,111 @@ def launch_ranks(a, jsonfd):
             % (a.gpus, d.get("n_gpus")))
         sys.exit(3)
     os.write(jsonfd, (line + "\n").encode())
+
+
+def c_path_mode(a, jsonfd):
+    """--path c: the product's own N > 1 path.  ONE process; vsa_multi_* drives
+    every GPU from a host thread of its own (libvstree_amd_multi.so, what
+    integration/vmengine_shim.c binds for VMATCH_GPUS=N): index replicated
+    device to device, the queries of a call cut into one block per GPU,
+    -mum candidates exchanged by peer copies and filtered per range, counters
+    through one ncclAllReduce.  The entry point takes queries in HOST memory
+    and returns the matches in HOST memory (the reference's Multiseq in,
+    processfinal out), so this line is PCIe-inclusive by construction and is
+    named accordingly; it is not the headline metric."""
+    import vstree_amd as V
+    from vstree_amd import multi as M
+    n, nq, m, L = int(a.genome), int(a.queries), a.qlen, a.minlen
+    N = a.gpus
+    have = V.device_count()
+    if a.replicas_on_one_gpu:
+        devices = [0] * N
+    else:
+        if have < N:
+            log("bench.py: --path c --gpus %d, but %d GPU(s) here" % (N, have))
+            sys.exit(2)
+        devices = list(range(N))
+    t0 = time.time()
+    dg = V.device_malloc(n + 64, 0)
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, n, dg, 0))
+    index = V.Index.build_device(dg, n, 4, 0, 0)
+    info = index.info()
+    # the queries of the whole job in host memory, as a reference caller
+    # holds them
+    pos, sub, step = V.synth_query_plan(n, nq * N, m)
+    hq = np.empty(nq * N * m, np.uint8)
+    dq = V.device_malloc(nq * m + 64, 0)
+    for r in range(N):
+        sl = slice(r * nq, (r + 1) * nq)
+        ps, sb, st = (np.ascontiguousarray(x[sl]) for x in (pos, sub, step))
+        V._check(V.lib.vsa_synth_queries_device(
+            dg, n, ps.ctypes.data, sb.ctypes.data, st.ctypes.data, nq, m, dq,
+            0))
+        V.device_download(hq[r * nq * m:(r + 1) * nq * m], dq, 0)
+    V.device_free(dq, 0)
+    V.device_free(dg, 0)
+    t1 = time.time()
+    multi = M.Multi.replicate(index, devices)
+    t_rep = time.time() - t1
+    log("setup: index %d bp built in %.1fs, %d replica(s) in %.1fs"
+        % (n, t1 - t0, N, t_rep))
+    start = np.arange(nq * N, dtype=np.uint64) * m
+    length = np.full(nq * N, m, np.uint64)
+    st = None
+    for _ in range(a.warmup):
+        mm, st, rc, msg = multi.findmatches(M.MUM, hq, start, length, L)
+        if rc != 0:
+            raise RuntimeError(msg)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        mm, st, rc, msg = multi.findmatches(M.MUM, hq, start, length, L)
+        if rc != 0:
+            raise RuntimeError(msg)
+    elapsed = time.perf_counter() - t0
+    out = {
+        "metric": "queries/sec, host memory to host memory through "
+                  "vsa_multi_findmatches (100 bp queries, vmatch -mum -l 20, "
+                  "3 Gbp ESA index replicated in HBM) -- PCIe-inclusive, one "
+                  "process, one host thread per GPU",
+        "value": nq * N * a.steps / elapsed, "unit": "queries/s",
+        "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "3 Gbp synthetic DNA index, 10 M x 100 bp "
+                               "queries per GPU in host memory, -mum -l 20, "
+                               "C entry point of the N > 1 path",
+                   "index_bp": n, "queries_per_gpu": nq, "query_len": m,
+                   "minlen": L, "devices": devices,
+                   "replicas_on_one_gpu": bool(a.replicas_on_one_gpu),
+                   "index_replication_s": round(t_rep, 2),
+                   "parallelism": "index replicated, queries in %d blocks"
+                                  % N},
+        "rccl_ranks": N if multi.uses_rccl() else 0,
+        "matches": int(st.count), "candidates": int(st.candidates),
+        "query_suffix_searches": int(st.searches),
+        "bytes_over_pcie_per_step": int(nq * N * m + 16 * nq * N +
+                                        32 * int(st.count)),
+    }
+    multi.close()
+    os.write(jsonfd, (json.dumps(out) + "\n").encode())
+
+
+def physical_cores():
+    """(sockets x cores per socket, what lscpu said)"""
+    try:
+        txt = subprocess.run(["lscpu"], stdout=subprocess.PIPE).stdout.decode()
+        f = {}
+        for l in txt.splitlines():
+            if ":" in l:
+                k, v = l.split(":", 1)
+                f[k.strip()] = v.strip()
+        p = int(f["Socket(s)"]) * int(f["Core(s) per socket"])
+        return p, "lscpu: %s socket(s) x %s cores, %s threads per core, %s" % (
+            f["Socket(s)"], f["Core(s) per socket"],
+            f.get("Thread(s) per core", "?"), f.get("Model name", "?"))
+    except Exception as e:      # no lscpu, unexpected output
+        return None, "lscpu unavailable (%r)" % (e,)
 
 
 def selfmum_text(V, n):
@@ -534,6 +669,11 @@ def main():
         if world == 1 else sumlength / (elapsed / a.steps) / 1e9,
         "matches": count, "candidates": candidates,
         "query_suffix_searches": searches,
+        # ranks of the RCCL communicator the counters went through (0: one
+        # process, no collective; gloo in the one-GPU rehearsal is not RCCL)
+        "rccl_ranks": (dist.get_world_size()
+                       if distributed and not a.rehearse_on_one_gpu else 0),
+        "ranks": world,
     }
 
     if rank == 0:
@@ -542,21 +682,62 @@ def main():
         t = index.download()
         host = H.Index(n, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
                        t["llv"], t["bck"], t["bwt"], None)
+        pphys = physical_cores()[0] or 0
         nsample = min(nq, max(a.cpu_sample, a.ref_sample if extras else 0,
+                              min(pphys, len(os.sched_getaffinity(0))) *
+                              125000 if extras and not a.no_reference else 0,
                               20000))
         qsym = np.zeros(nsample * m, np.uint8)
         g = t["tis"]
         rows = qsym.reshape(nsample, m)
-        idx = pos[:nsample, None].astype(np.int64) + np.arange(m)[None, :]
-        rows[:] = g[idx]            # the same queries the GPU has
+        for c0 in range(0, nsample, 1 << 20):   # the same queries the GPU has
+            c1 = min(nsample, c0 + (1 << 20))
+            idx = pos[c0:c1, None].astype(np.int64) + np.arange(m)[None, :]
+            rows[c0:c1] = g[idx]
+            del idx
         hit = np.flatnonzero(sub[:nsample] != V.NO_SUBST)
         rows[hit, sub[hit]] = (rows[hit, sub[hit]] + step[hit]) & 3
-        del idx
         small = H.Queries.uniform(qsym[:20000 * m], m)
         bytes_per_query, counters = count_bytes(
             H, lambda: H.oracle_querymatches(host, small, L, mum=True,
                                              cand=True, speedup=0),
             small.nq, w, int(small.length.sum()))
+        # ... and counted on exactly the searches the dominant kernel runs:
+        # the plans of the first queries as the engine made them (one more
+        # call with VSA_DEBUG_PLANFILE, outside the timed region), every
+        # planned (query, offset) searched by the instrumented restatement
+        counted_per_search = counted_items = None
+        if not distributed:
+            pf = os.path.join(a.workdir, "vsa_plans_%d.bin" % os.getpid())
+            os.environ["VSA_DEBUG_PLANFILE"] = pf
+            try:
+                V.findquerymatches(index, queries, L, mum=True).close()
+            finally:
+                del os.environ["VSA_DEBUG_PLANFILE"]
+            if os.path.exists(pf):
+                pl = np.fromfile(pf, np.uint32).reshape(-1, 5)[:small.nq]
+                os.unlink(pf)
+                qi, offs = [], []
+                for k in range(1, 5):
+                    first, ln = pl[:, k] & 0xFFFF, pl[:, k] >> 16
+                    ln = np.where(pl[:, 0] != 0, ln, 0)
+                    rep = np.repeat(np.arange(len(pl)), ln)
+                    within = np.arange(ln.sum()) - np.repeat(
+                        np.cumsum(ln) - ln, ln)
+                    qi.append(rep)
+                    offs.append(first[rep] + within)
+                qi, offs = np.concatenate(qi), np.concatenate(offs)
+                if len(qi):
+                    lens = (m - offs).astype(np.uint64)
+                    starts = (qi * m + offs).astype(np.uint64)
+                    sufq = H.Queries(small.symbols, starts, lens)
+                    cb, _ = count_bytes(H, lambda: H.oracle_complete(host, sufq),
+                                        len(qi), w, int(lens.sum()))
+                    # (count_bytes charges every search its whole suffix as
+                    # "query symbols"; a search reads the ones it compares,
+                    # which `charcomp` holds already)
+                    counted_per_search = cb - float(lens.sum()) / len(qi)
+                    counted_items = int(len(qi))
         # SURVEY 8d / BASELINE.md: bytes of the reference's per-suffix
         # algorithm (one bucket lookup + binary search for EVERY query
         # suffix) x queries per launch
@@ -568,7 +749,18 @@ def main():
         main_searches = kernel_searches
         executed_bytes_launch = alg0_bytes_launch * (
             (main_searches / world) / full_searches)
+        bytes_are = "modelled"
+        if counted_per_search is not None:
+            executed_bytes_launch = counted_per_search * main_searches / world
+            bytes_are = "counted"
         achieved = executed_bytes_launch / (kms * 1e-3) / 1e9
+        # the rate at which THIS device delivers random 64-byte sectors of the
+        # table every search starts in (vsa_measure_table_read on slot16,
+        # disjoint address sequences per lane): the ceiling of a kernel whose
+        # loads are random 16-byte slots -- 39 % of the streaming peak
+        rnd = C.c_double(0.0)
+        rc = V.lib.vsa_measure_table_read(index._h, 0, 4, C.byref(rnd))
+        random_gs = rnd.value if rc == 0 else None
         # HBM bytes of the dominant kernel from the PMC passes of this very
         # kernel source (scripts/pmc_passes.sh writes the file; a profile of
         # other sources is not quoted)
@@ -586,16 +778,36 @@ def main():
             "algorithmic_bytes_per_query_all_suffixes": bytes_per_query,
             "achieved_if_priced_on_all_suffixes":
                 alg0_bytes_launch / (kms * 1e-3) / 1e9,
-            "bytes_are": "modelled",
+            "bytes_are": bytes_are,
+            "bytes_per_search": executed_bytes_launch / max(
+                main_searches / world, 1),
+            "searches_counted": counted_items,
             "note": "kernel_ms: HIP events around the kernel, this run. "
-                    "algorithmic bytes = SURVEY 8d formula counted by the "
-                    "instrumented CPU restatement (%.1f kB per 100 bp query "
-                    "for all 81 suffixes) scaled to the %.1f%% of the "
-                    "suffix searches this kernel executes after the first "
-                    "pass and the work plan; the path is random 8/16-byte "
-                    "reads, one 64-byte sector each, see DESIGN.md"
-                    % (bytes_per_query / 1e3,
-                       100.0 * main_searches / world / full_searches)}
+                    "algorithmic bytes = SURVEY 8d formula (2w bucket + w "
+                    "per probe + compared symbols + lcp entries + w + 17 per "
+                    "hit) counted by the instrumented CPU restatement on the "
+                    "(query, offset) searches this kernel runs for the first "
+                    "20 000 queries (their plans dumped by the engine), x "
+                    "the kernel's searches (%.1f%% of the %d per query: the "
+                    "first pass and the work plan prove the others "
+                    "unnecessary; all of them: %.1f kB per query); the path "
+                    "is random 16-byte slots, one 64-byte sector each"
+                    % (100.0 * main_searches / world / full_searches,
+                       m - L + 1, bytes_per_query / 1e3)}
+        if random_gs:
+            sect = (traffic / 64.0) if traffic else None
+            out["roofline"]["random_sector_ceiling"] = {
+                "measured_G_sectors_per_s": random_gs,
+                "GBs_of_64B_sectors": random_gs * 64,
+                "frac_of_hbm_peak": random_gs * 64 / HBM_PEAK_GBS,
+                "kernel_G_sectors_per_s":
+                    sect / (kms * 1e-3) / 1e9 if sect else None,
+                "kernel_frac_of_ceiling":
+                    sect / (kms * 1e-3) / 1e9 / random_gs if sect else None,
+                "note": "random 16-byte reads of the slot table, 4 in flight "
+                        "per lane, every lane its own address sequence "
+                        "(vsa_measure_table_read); the kernel's sectors = "
+                        "PMC traffic / 64"}
         fams = []
         if world == 1:
             # every query once, with the whole query: priced like the
@@ -621,7 +833,26 @@ def main():
                 a, V, H, index, host, qsym, m, L, dev, qps,
                 free_index=lambda: index.close())
         if extras:
-            fams.append(selfmum_family(a, V, n, L, dev))
+            k3 = selfmum_family(a, V, n, L, dev)
+            fams.append(k3)
+            # north_star's "suftab scan": where the driver's record keeps it
+            out["roofline"]["suftab_scan"] = {
+                k: k3[k] for k in ("kernel", "mode", "bound", "achieved",
+                                   "peak", "unit", "frac", "traffic",
+                                   "kernel_ms", "algorithmic_bytes_per_launch",
+                                   "note") if k in k3}
+        tj = pmc_traffic(n, nq)
+        if tj.get("step_hbm_bytes"):
+            sb = tj["step_hbm_bytes"]
+            out["roofline"]["step"] = {
+                "hbm_bytes_per_step": sb,
+                "achieved": sb / (out["ms_per_step"] * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": sb / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "HBM bytes of ALL kernels of one step (PMC FETCH_SIZE "
+                        "+ WRITE_SIZE of a run with two steps minus a run "
+                        "with one, %s) / ms_per_step of this run"
+                        % tj.get("source")}
         sys.stdout.flush()
         os.write(jsonfd, (json.dumps(out) + "\n").encode())
     if distributed:
@@ -825,6 +1056,9 @@ def cpu_baselines(a, V, H, index, host, qsym, m, L, dev, qps, free_index):
         return port
     refb["port_1core"] = port
     refb["gpu_over_reference_all_cores"] = qps / refb["value"]
+    if refb.get("reference_physical_cores"):
+        refb["gpu_over_reference_physical_cores"] = \
+            qps / refb["reference_physical_cores"]["value"]
     refb["gpu_over_reference_1core"] = qps / refb["reference_1core"]["value"]
     return refb
 

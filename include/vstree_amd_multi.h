@@ -63,7 +63,9 @@ int vsa_multi_uses_rccl(const vsa_multi *multi);
 
 /*
   One engine call over all replicas.  Queries as for vsa_queries_from_host
-  (symbols / start / length of a Multiseq, host memory).  The matches come
+  (symbols / start / length of a Multiseq, host memory; any order in the
+  buffer; a query that does not lie inside the nsymbols given is refused
+  with -2 before anything is uploaded).  The matches come
   back in host memory (free with vsa_multi_free_matches), in the reference's
   order; total = the counters of the whole job (count, sumlength, searches,
   candidates).  Errors as in the single-GPU calls, incl. the reference's

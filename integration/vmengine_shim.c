@@ -69,6 +69,9 @@ Sint __real_findmaximaluniquematches(Virtualtree *, Uint, Uint, void *,
                                      void *, Outputfunction);
 
 static vsa_index *gpuindex = NULL;
+/* the replicas of VMATCH_GPUS / VMATCH_GPU_DEVICES (see multidevices) */
+static vsa_multi *gpumulti = NULL;
+static Virtualtree *gpumultiowner = NULL;
 static Virtualtree *gpuindexowner = NULL;
 
 static int usegpu(void)
@@ -120,6 +123,14 @@ static int getgpuindex(Virtualtree *virtualtree, int needbwt,
   if (gpuindex != NULL && gpuindexowner == virtualtree)
   {
     *index = gpuindex;
+    return 0;
+  }
+  if (gpumulti != NULL && gpumultiowner == virtualtree &&
+      (!needbwt || virtualtree->bwttab == NULL))
+  {
+    /* the replicas are there (an exact call ran on all GPUs): replica 0 serves
+       the single-GPU paths, the index is not uploaded a second time */
+    *index = vsa_multi_index(gpumulti, 0);
     return 0;
   }
   if (gpuindex != NULL)
@@ -208,19 +219,32 @@ static int getgpuqueries(Multiseq *multiseq, BOOL rcmode,
    queries are cut into blocks, the match lists come back in the reference's
    order and go through the same sinks as in the single-GPU case. */
 #define MAXGPUS 64
-static vsa_multi *gpumulti = NULL;
-static Virtualtree *gpumultiowner = NULL;
 
 static uint32_t multidevices(int *devices)
 {
   const char *list = getenv("VMATCH_GPU_DEVICES"), *n = getenv("VMATCH_GPUS");
   uint32_t count = 0;
 
+  const int have = vsa_device_count();
+
   if (list != NULL && *list != '\0')
   {
-    while (*list != '\0' && count < MAXGPUS)
+    while (*list != '\0')
     {
-      devices[count++] = (int) strtol(list, (char **) &list, 10);
+      char *end = NULL;
+      const long id = strtol(list, &end, 10);
+      if (end == list || id < 0 || id >= have || count >= MAXGPUS)
+      {
+        /* no digits here (a token such as "a", ";"), a device that does not
+           exist, or more replicas than the table holds: say so and stop --
+           never guess a device */
+        fprintf(stderr, "%s: VMATCH_GPU_DEVICES=\"%s\": expected up to %d "
+                "device numbers below %d, separated by commas\n",
+                "vmatch", getenv("VMATCH_GPU_DEVICES"), MAXGPUS, have);
+        exit(EXIT_FAILURE);
+      }
+      devices[count++] = (int) id;
+      list = end;
       while (*list == ',' || *list == ' ')
       {
         list++;
@@ -228,7 +252,13 @@ static uint32_t multidevices(int *devices)
     }
   } else if (n != NULL && atoi(n) > 1)
   {
-    for (count = 0; count < (uint32_t) atoi(n) && count < MAXGPUS; count++)
+    if (atoi(n) > have || atoi(n) > MAXGPUS)
+    {
+      fprintf(stderr, "%s: VMATCH_GPUS=%s, but this node shows %d GPU(s)\n",
+              "vmatch", n, have);
+      exit(EXIT_FAILURE);
+    }
+    for (count = 0; count < (uint32_t) atoi(n); count++)
     {
       devices[count] = (int) count;
     }
@@ -250,6 +280,13 @@ static int getgpumulti(Virtualtree *virtualtree, const int *devices,
   {
     vsa_multi_close(gpumulti);
     gpumulti = NULL;
+  }
+  if (gpuindex != NULL)
+  {
+    /* (replica 0 takes its place: one copy of the index per device) */
+    vsa_index_close(gpuindex);
+    gpuindex = NULL;
+    gpuindexowner = NULL;
   }
   memset(&t, 0, sizeof t);
   t.totallength = virtualtree->multiseq.totallength;

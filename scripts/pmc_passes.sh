@@ -11,8 +11,15 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $line --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 "$@" > $R/gpurun_out/$OUT/p$i.json 2> $R/gpurun_out/$OUT/p$i.err
-  echo "pass $i rc=$? : $line" >> $R/gpurun_out/$OUT/progress.log
+  # a line that starts with "2 " runs two steps: the difference to the pass
+  # with one step is the traffic of exactly one step (pmc_summary.py)
+  steps=1
+  case "$line" in "2 "*) steps=2; line=${line#2 };; esac
+  echo $steps > $R/gpurun_out/$OUT/p$i.steps
+  timeout -k 10 150 rocprofv3 --pmc $line --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps $steps --warmup 0 --cpu-sample 0 "$@" > $R/gpurun_out/$OUT/p$i.json 2> $R/gpurun_out/$OUT/p$i.err
+  rc=$?
+  echo "pass $i rc=$rc : $line" >> $R/gpurun_out/$OUT/progress.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then break; fi
 done <<'PASSES'
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
@@ -20,5 +27,7 @@ TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum T
 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum
 FETCH_SIZE
 TCC_HIT_sum TCC_MISS_sum WRITE_SIZE
+2 FETCH_SIZE
+2 WRITE_SIZE
 PASSES
 cat $R/gpurun_out/$OUT/progress.log

@@ -26,11 +26,36 @@ def main():
     traffic = sys.argv[4] if len(sys.argv) > 4 else None
     sums = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
+    # passes that ran two steps (pmc_passes.sh, "2 COUNTER"): only for the
+    # traffic of one whole step = totals(two steps) - totals(one step)
+    two = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in sorted(glob.glob(d + "/p*/*/*counter_collection.csv")):
+        pdir = f[len(d) + 1:].split("/")[0]
+        marker = os.path.join(d, pdir + ".steps")
+        steps = int(open(marker).read()) if os.path.exists(marker) else 1
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
+            if steps == 2:
+                two[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                continue
             sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[k][r["Counter_Name"]] += 1
+    step_bytes = None
+    if two:
+        # FETCH_SIZE counts wide coalesced reads at half their size on gfx950
+        # (MI355X_MICROARCH.md): doubled for every kernel but the searches,
+        # whose reads are random 8/16-byte words, one 64-byte request each
+        random = ("k_mum_first", "k_mum_plan", "k_query_search",
+                  "k_complete_search", "k_mum_anchor")
+        step_bytes, per_kernel = 0.0, {}
+        for k in two:
+            f2 = two[k].get("FETCH_SIZE", 0.0) - sums[k].get("FETCH_SIZE", 0.0)
+            w2 = two[k].get("WRITE_SIZE", 0.0) - sums[k].get("WRITE_SIZE", 0.0)
+            fac = 1 if k.startswith(random) else 2
+            b = (max(f2, 0.0) * fac + max(w2, 0.0)) * 1024
+            if b > 0:
+                per_kernel[k] = b
+            step_bytes += b
     counters = sorted({c for k in sums for c in sums[k]})
     want = [k for k in sums if k.startswith("k_") or "k_" in k]
     lines = ["rocprofv3 --pmc, one pass per counter group (scripts/"
@@ -67,7 +92,11 @@ def main():
                          "miss); the x2 correction of MI355X_MICROARCH.md "
                          "for wide coalesced streams is not applied",
                  "kernel_source_sha16": kernel_source_hash(),
-                 "round": 2, "source": out}
+                 "round": 3, "source": out}
+            if step_bytes:
+                j["step_hbm_bytes"] = step_bytes
+                j["step_hbm_bytes_by_kernel"] = dict(sorted(
+                    per_kernel.items(), key=lambda kv: -kv[1])[:16])
             # the other kernel families bench.py prices: (FETCH_SIZE +
             # WRITE_SIZE) KiB per launch.  Streaming kernels read in wide
             # coalesced requests, which FETCH_SIZE counts at half their size on

@@ -163,3 +163,90 @@ def test_two_processes_on_one_gpu_run_the_exchange_for_real(tmp_path):
     assert a["matches"] == b["matches"] > 250000
     assert a["candidates"] == b["candidates"] >= a["matches"]
     assert a["query_suffix_searches"] == b["query_suffix_searches"]
+
+
+def test_bench_started_directly_with_two_gpus_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how a driver
+    starts the scaling run) must end up on two ranks, or not print a line at
+    all -- never a line for one GPU."""
+    import json
+    import subprocess
+    import sys
+    bench = H.os.path.join(H.ROOT, "bench.py")
+    common = ["--genome", "3e7", "--queries", "150000", "--steps", "2",
+              "--warmup", "1", "--quick", "--cpu-sample", "0"]
+    two = subprocess.run([sys.executable, bench, "--gpus", "2",
+                          "--rehearse-on-one-gpu"] + common,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=600)
+    assert two.returncode == 0, two.stderr.decode()[-2000:]
+    lines = [l for l in two.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    a = json.loads(lines[0])
+    assert a["n_gpus"] == 2 and a["ranks"] == 2
+    assert a["rccl_ranks"] == 0      # gloo on host copies in the rehearsal
+    # more GPUs than the box has, no rehearsal: refusal, no line
+    many = subprocess.run([sys.executable, bench, "--gpus", "7"] + common,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=600)
+    assert many.returncode != 0 and many.stdout.decode().strip() == ""
+    # a rank count that does not match --gpus: refusal as well
+    env = dict(H.os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    odd = subprocess.run([sys.executable, bench, "--gpus", "2"] + common,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=600, env=env)
+    assert odd.returncode != 0 and odd.stdout.decode().strip() == ""
+
+
+def test_bench_c_path_with_replicas_on_one_gpu():
+    """--path c: vsa_multi_findmatches (the product's N > 1 entry) timed from
+    one process, here with two replicas on device 0; counters = one GPU's."""
+    import json
+    import subprocess
+    import sys
+    bench = H.os.path.join(H.ROOT, "bench.py")
+    common = ["--genome", "3e7", "--steps", "2", "--warmup", "1", "--quick",
+              "--cpu-sample", "0"]
+    c = subprocess.run([sys.executable, bench, "--gpus", "2", "--path", "c",
+                        "--replicas-on-one-gpu", "--queries", "150000"] +
+                       common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert c.returncode == 0, c.stderr.decode()[-2000:]
+    a = json.loads(c.stdout.decode().strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, bench, "--queries", "300000"] +
+                         common, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    b = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    assert a["n_gpus"] == 2 and "host memory" in a["metric"]
+    assert a["matches"] == b["matches"] > 250000
+    assert a["candidates"] == b["candidates"]
+
+
+def test_queries_in_any_order_and_outside_the_buffer(V, MG):
+    """a Multiseq's queries need not lie in ascending order in the buffer
+    (vsa_queries_from_host takes any order): every block is uploaded from the
+    lowest start to the highest end of ITS queries; a query that reaches
+    beyond nsymbols is refused before anything is read"""
+    idx, q, m = tables(MG, "c1", [0, 0, 0])
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(q.nq)
+    # the same symbols, the queries listed in another order: query i of the
+    # call is query perm[i] of the golden case
+    start, length = q.start[perm], q.length[perm]
+    got, st, rc, msg = m.findmatches(MG.COMPLETE, q.symbols, start, length)
+    assert rc == 0, msg
+    want = H.oracle_complete(idx, H.Queries(q.symbols, start, length))
+    assert np.array_equal(got.view(np.uint64).reshape(-1, 4),
+                          np.asarray(want).view(np.uint64).reshape(-1, 4))
+    got, st, rc, msg = m.findmatches(MG.MUM, q.symbols, start, length, 20)
+    assert rc == 0, msg
+    want = H.oracle_querymatches(idx, H.Queries(q.symbols, start, length), 20,
+                                 mum=True)
+    assert np.array_equal(got.view(np.uint64).reshape(-1, 4),
+                          np.asarray(want).view(np.uint64).reshape(-1, 4))
+    bad = length.copy()
+    bad[7] = len(q.symbols)          # runs past the end of the buffer
+    got, st, rc, msg = m.findmatches(MG.COMPLETE, q.symbols, start, bad)
+    assert rc == -2 and "query 7" in msg and len(got) == 0
+    m.close()

@@ -45,7 +45,10 @@ struct Cached
 std::mutex g_lock;
 std::unordered_map<void *, Block> g_live;                   // handed out
 std::map<std::pair<int, size_t>, std::vector<Cached>> g_free; // cached
-std::vector<hipEvent_t> g_events;                           // spare events
+// spare events, per device: an event belongs to the device it was made on
+// (one thread per GPU in vsa_multi_*: an event of device A recorded on a stream
+// of device B fails, and the fallback is a device-wide wait)
+std::map<int, std::vector<hipEvent_t>> g_events;
 size_t g_cached = 0;
 thread_local hipStream_t t_stream = nullptr;
 
@@ -137,10 +140,11 @@ int vsa_dev_alloc(void **ptr, size_t bytes)
         hipEvent_t ev = nullptr;
         {
           std::lock_guard<std::mutex> g2(g_lock);
-          if (!g_events.empty())
+          std::vector<hipEvent_t> &spare = g_events[device];
+          if (!spare.empty())
           {
-            ev = g_events.back();
-            g_events.pop_back();
+            ev = spare.back();
+            spare.pop_back();
           }
         }
         if (ev == nullptr &&
@@ -158,7 +162,7 @@ int vsa_dev_alloc(void **ptr, size_t bytes)
         if (ev != nullptr)
         {
           std::lock_guard<std::mutex> g2(g_lock);
-          g_events.push_back(ev); // the wait holds its own reference
+          g_events[device].push_back(ev); // the wait holds its own reference
         }
       }
       return 0;
@@ -204,24 +208,26 @@ void vsa_dev_free(void *ptr)
   {
     return;
   }
-  std::lock_guard<std::mutex> g(g_lock);
-  auto it = g_live.find(ptr);
-  if (it == g_live.end())
   {
-    // not ours (allocated with plain hipMalloc)
-    (void) hipFree(ptr);
-    return;
+    std::lock_guard<std::mutex> g(g_lock);
+    auto it = g_live.find(ptr);
+    if (it != g_live.end())
+    {
+      const Block b = it->second;
+      g_live.erase(it);
+      if (b.cls <= kMaxCachedBlock && g_cached + b.cls <= kMaxCachedTotal)
+      {
+        g_free[std::make_pair(b.device, b.cls)].push_back(
+            Cached{ptr, b.stream, true});
+        g_cached += b.cls;
+        return;
+      }
+    }
+    // not ours (allocated with plain hipMalloc), too large or the cache is
+    // full: back to HIP -- outside the lock, hipFree waits for the device and
+    // the replica threads of the other GPUs must not wait with it
   }
-  const Block b = it->second;
-  g_live.erase(it);
-  if (b.cls > kMaxCachedBlock || g_cached + b.cls > kMaxCachedTotal)
-  {
-    (void) hipFree(ptr); // synchronises the device
-    return;
-  }
-  g_free[std::make_pair(b.device, b.cls)].push_back(
-      Cached{ptr, b.stream, true});
-  g_cached += b.cls;
+  (void) hipFree(ptr);
 }
 
 void vsa_dev_trim()

@@ -1206,6 +1206,29 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         VSA_HIP(hipGetLastError());
       }
       plansearches = 2 * nlist;
+      if (const char *pf = getenv("VSA_DEBUG_PLANFILE"))
+      {
+        // the plans of the first 65 536 queries as they stand when the search
+        // kernel starts -- per query its count and VSA_PLAN_RANGES ranges
+        // (first | length << 16), 32-bit words -- for bench.py, which prices
+        // the kernel on exactly the searches it runs
+        const uint64_t k = std::min<uint64_t>(nq, 65536);
+        std::vector<uint32_t> hc(k), hp(k * VSA_PLAN_RANGES);
+        VSA_HIP(hipMemcpyAsync(hc.data(), wcount.p, k * 4,
+                               hipMemcpyDeviceToHost, stream));
+        VSA_HIP(hipMemcpyAsync(hp.data(), wplan.p, k * sizeof(PlanRanges),
+                               hipMemcpyDeviceToHost, stream));
+        VSA_HIP(hipStreamSynchronize(stream));
+        if (FILE *f = fopen(pf, "wb"))
+        {
+          for (uint64_t q = 0; q < k; q++)
+          {
+            (void) fwrite(&hc[q], 4, 1, f);
+            (void) fwrite(&hp[q * VSA_PLAN_RANGES], 4, VSA_PLAN_RANGES, f);
+          }
+          fclose(f);
+        }
+      }
       if (getenv("VSA_DEBUG_PLANHIST") != nullptr)
       {
         // how the work-items are spread over the planned reads (stderr)

@@ -224,12 +224,18 @@ void searchblock(const Job &job, uint32_t r, RankOut &o)
   }
   // the block's symbols: from the start of its first query to the end of its
   // last one; starts relative to that
+  // (the queries of a Multiseq may lie in any order in the buffer:
+  // vsa_multi_findmatches has checked every one against nsymbols)
   std::vector<uint64_t> st(count + 1), ln(count + 1);
   uint64_t lo = 0, hi = 0;
   if (count > 0)
   {
-    lo = job.start[first];
-    hi = job.start[first + count - 1] + job.length[first + count - 1];
+    lo = ~0ull;
+    for (uint64_t i = 0; i < count; i++)
+    {
+      lo = std::min(lo, job.start[first + i]);
+      hi = std::max(hi, job.start[first + i] + job.length[first + i]);
+    }
   }
   for (uint64_t i = 0; i < count; i++)
   {
@@ -539,6 +545,23 @@ extern "C" int vsa_multi_findmatches(vsa_multi *m, int mode,
   }
   *matches = nullptr;
   *count = 0;
+  // every query inside the caller's buffer (any order, overlaps allowed, as
+  // for vsa_queries_from_host): the blocks are uploaded from start/length
+  // alone, and nothing behind nsymbols is the library's to read
+  for (uint64_t i = 0; i < nq; i++)
+  {
+    if (start[i] > nsymbols || length[i] > nsymbols - start[i])
+    {
+      char msg[160];
+      snprintf(msg, sizeof msg,
+               "vsa_multi_findmatches: query %llu (start %llu, length %llu) "
+               "lies outside the %llu symbols given",
+               (unsigned long long) i, (unsigned long long) start[i],
+               (unsigned long long) length[i], (unsigned long long) nsymbols);
+      seterror(msg);
+      return -2;
+    }
+  }
   const uint32_t world = (uint32_t) m->dev.size();
   vsa_index_info info;
   if (vsa_index_getinfo(m->ix[0], &info) != 0)

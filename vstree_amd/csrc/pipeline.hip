@@ -232,6 +232,13 @@ void work(vsa_pipeline *p)
       s.res = res; // freed when the slot is handed back
       s.rc = rc;
       s.state = SLOT_DONE;
+      if (rc != 0 && p->mode == 3 && p->failed == 0)
+      {
+        // -mum: the candidates of this batch are missing from the job, and
+        // the filter over the rest would call matches unique that are not
+        p->failed = rc;
+        p->failure = s.message;
+      }
     }
     p->wake.notify_all();
   }
@@ -392,17 +399,30 @@ extern "C" int vsa_pipeline_submit(vsa_pipeline *p, uint64_t nq)
   Slot &s = p->slot[k];
   s.nq = nq;
   s.first = p->submitted;
-  p->submitted += nq;
   const uint64_t nsym = nq * (uint64_t) p->m;
   // what lies behind the last read must stop every comparison
   memset(s.hostq + nsym, 0xFF, VSA_QUERY_BACKPAD);
-  if (vsa_set_device(p->index->device) != 0)
+  // (a batch that could not be queued leaves the pipeline as it was: the
+  // buffer stays handed out, the numbering of the queries does not move)
+  hipError_t e = vsa_set_device(p->index->device) != 0 ? hipErrorInvalidDevice
+                                                       : hipSuccess;
+  if (e == hipSuccess)
   {
+    e = hipMemcpyAsync(s.q->symbols, s.hostq, nsym + VSA_QUERY_BACKPAD,
+                       hipMemcpyHostToDevice, p->up);
+  }
+  if (e == hipSuccess)
+  {
+    e = hipEventRecord(s.uploaded, p->up);
+  }
+  if (e != hipSuccess)
+  {
+    VSA_ERROR("vsa_pipeline_submit: upload failed: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> g(p->lock);
+    p->filling = k;
     return -100;
   }
-  VSA_HIP(hipMemcpyAsync(s.q->symbols, s.hostq, nsym + VSA_QUERY_BACKPAD,
-                         hipMemcpyHostToDevice, p->up));
-  VSA_HIP(hipEventRecord(s.uploaded, p->up));
+  p->submitted += nq;
   {
     std::lock_guard<std::mutex> g(p->lock);
     s.state = SLOT_SUBMITTED;
@@ -480,6 +500,21 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
       return -1;
     }
   }
+  {
+    std::lock_guard<std::mutex> g(p->lock);
+    if (p->failed != 0)
+    {
+      // a batch of this job failed: no list; the next job starts afresh
+      const int frc = p->failed;
+      VSA_ERROR("vsa_pipeline_finish: a batch of the job failed: %s",
+                p->failure.c_str());
+      p->failed = 0;
+      p->failure.clear();
+      p->nrows = 0;
+      p->candidates = 0;
+      return frc;
+    }
+  }
   if (vsa_set_device(p->index->device) != 0)
   {
     return -100;
@@ -490,6 +525,8 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
       &res);
   if (rc != 0)
   {
+    p->nrows = 0; // (whatever the outcome, the next job starts afresh)
+    p->candidates = 0;
     return rc;
   }
   const uint64_t c = vsa_result_count(res);

@@ -82,13 +82,13 @@ def _exchange_rows(dist, torch, rows, dest, device):
     rows = rows[order].contiguous()
     send = torch.bincount(dest, minlength=world).to(torch.int64)
     recv = torch.zeros_like(send)
-    try:
+    if dist.get_backend() == "nccl":   # (decided alike on every rank)
         dist.all_to_all_single(recv, send)
         out = torch.empty((int(recv.sum().item()), MATCH_WORDS),
                           dtype=torch.int64, device=device)
         dist.all_to_all_single(out, rows, recv.tolist(), send.tolist())
         return out
-    except (RuntimeError, NotImplementedError):
+    else:
         # backend without all-to-all (gloo in the CPU tests): gather all,
         # keep what is addressed to this rank
         parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device)
@@ -122,13 +122,18 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     meta = torch.as_tensor(np.concatenate([np.asarray(send, np.int64),
                                            np.asarray(maxright, np.int64)]),
                            device=device)
-    try:
+    # which collectives the backend has is a property of the process group,
+    # decided the same way on every rank before anything is sent (a fallback
+    # inside `except` would let ranks that fail for another reason issue a
+    # different collective than the others)
+    rccl = dist.get_backend() == "nccl"
+    if rccl:
         # one tensor in, one out: no list of outputs to allocate and stack
         gathered = torch.empty(world * meta.numel(), dtype=meta.dtype,
                                device=device)
         dist.all_gather_into_tensor(gathered, meta)
         table = gathered.reshape(world, -1).cpu().numpy()   # [sender, 2*world]
-    except (RuntimeError, NotImplementedError, AttributeError):
+    else:
         metas = [torch.zeros_like(meta) for _ in range(world)]
         dist.all_gather(metas, meta)
         table = torch.stack(metas).cpu().numpy()
@@ -137,10 +142,10 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     # largest right end among ALL candidates of the ranges below mine
     carry = int(tops[:, :me].max()) if me > 0 else 0
     mine = torch.empty((sum(recv), words), dtype=torch.int64, device=device)
-    try:
+    if rccl:
         dist.all_to_all_single(mine, rows, recv,
                                [int(x) for x in sends[me]])
-    except (RuntimeError, NotImplementedError):
+    else:
         # backend without all-to-all (gloo in the CPU tests): gather all,
         # cut out what is addressed to this rank
         parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device,
