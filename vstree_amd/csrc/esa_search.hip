@@ -786,9 +786,23 @@ int mumfilter_packed(KeyIn keys_in, ValIn vals_in, uint64_t ncand,
   }
   DevBuf k2, v2, dbright, keep, slots, temp, dcount, blocksum;
   const size_t nblocks = blocksfor(ncand);
+  // the passes behind the sort by tiles (mum_filter.inc; VSA_FILTER_TILES=0:
+  // the rocPRIM scans of round 2)
+  const char *tilesenv = getenv("VSA_FILTER_TILES");
+  const bool bytiles = !(tilesenv != nullptr && strcmp(tilesenv, "0") == 0);
+  const uint64_t ntiles = (ncand + VSA_FT_TILE - 1) / VSA_FT_TILE;
+  DevBuf tmax, tcarry, tcount, toff, tsum, tsumscan;
+  if (bytiles &&
+      (tmax.alloc((ntiles + 1) * 8) || tcarry.alloc((ntiles + 1) * 8) ||
+       tcount.alloc((ntiles + 1) * 8) || toff.alloc((ntiles + 1) * 8) ||
+       tsum.alloc((ntiles + 1) * 8) || tsumscan.alloc((ntiles + 1) * 8)))
+  {
+    return -100;
+  }
   if (k2.alloc(ncand * 8) || v2.alloc(ncand * sizeof(VAL)) ||
-      dbright.alloc(ncand * 8) ||
-      keep.alloc(ncand) || slots.alloc(ncand * 4) || dcount.alloc(24) ||
+      (!bytiles && dbright.alloc(ncand * 8)) ||
+      keep.alloc(ntiles * VSA_FT_TILE) ||
+      (!bytiles && slots.alloc(ncand * 4)) || dcount.alloc(24) ||
       blocksum.alloc(vsa_grid_blocks(nblocks) * 8) ||
       mums.alloc(ncand * sizeof(vsa_match)))
   {
@@ -815,6 +829,46 @@ int mumfilter_packed(KeyIn keys_in, ValIn vals_in, uint64_t ncand,
     VSA_HIP(rocprim::radix_sort_pairs(
         temp.p, tb, keys_in, k2.as<uint64_t>(), vals_in,
         v2.as<VAL>(), (size_t) ncand, firstbit, lenbits + dbbits, stream));
+    if (byruns && bytiles)
+    {
+      const dim3 tg = vsa_grid(ntiles);
+      k_mumf_tilemax<<<tg, VSA_BLOCK, 0, stream>>>(
+          k2.as<uint64_t>(), ncand, lenbits, tmax.as<uint64_t>());
+      k_mumf_scan<1><<<1, VSA_BLOCK, 0, stream>>>(
+          tmax.as<uint64_t>(), ntiles, carry, tcarry.as<uint64_t>());
+      k_mumf_flags<<<tg, VSA_BLOCK, 0, stream>>>(
+          k2.as<uint64_t>(), ncand, lenbits, tcarry.as<uint64_t>(),
+          keep.as<uint8_t>(), tcount.as<uint64_t>(), tsum.as<uint64_t>(),
+          dcount.as<unsigned int>() + 4);
+      // (offsets of the tiles and, in a second workgroup, the sum of the
+      // lengths)
+      k_mumf_scan<0><<<2, VSA_BLOCK, 0, stream>>>(
+          tcount.as<uint64_t>(), ntiles, 0, toff.as<uint64_t>(),
+          tsum.as<uint64_t>(), tsumscan.as<uint64_t>());
+      k_mumf_write<VAL><<<tg, VSA_BLOCK, 0, stream>>>(
+          k2.as<uint64_t>(), v2.as<VAL>(), keep.as<uint8_t>(), ncand,
+          toff.as<uint64_t>(), lenbits, valbits, seqoffset,
+          mums.as<vsa_match>());
+      VSA_HIP(hipGetLastError());
+      // number of MUMs, sum of their lengths, "a run was too long"
+      const Fetch f[3] = {{toff.as<uint64_t>() + ntiles, 8},
+                          {tsumscan.as<uint64_t>() + ntiles, 8},
+                          {dcount.as<uint64_t>() + 2, 8}};
+      if (fetchwords(stream, f, 3, got))
+      {
+        return -100;
+      }
+      if (got[2] == 0)
+      {
+        break;
+      }
+      continue;
+    }
+    if (dbright.p == nullptr &&
+        (dbright.alloc(ncand * 8) || slots.alloc(ncand * 4)))
+    {
+      return -100;
+    }
     // running maximum of the right ends, which are a function of the keys
     auto ends = rocprim::make_transform_iterator(k2.as<uint64_t>(),
                                                  KeyToRightEnd{lenbits});
