@@ -273,7 +273,7 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
                 for p in range(ncores):
                     with open(wd + "/qp%d.fna" % p, "rb") as g:
                         shutil.copyfileobj(g, f)
-            genv = dict(os.environ, VMATCH_GPU_TRACE="1")
+            genv = dict(os.environ, VMATCH_GPU_TRACE="1", VSA_TRACE="1")
             td = time.time()
             pr = subprocess.run([gpubin, "-mum", "-l", str(L), "-q",
                                  "qall.fna", "genome.fna"], cwd=wd, env=genv,

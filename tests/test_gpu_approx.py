@@ -27,11 +27,12 @@ def without_special_queries(q):
     return keep, H.Queries(q.symbols, q.start[keep], q.length[keep])
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])
 @pytest.mark.parametrize("case,key", APPROX)
-def test_gpu_reproduces_reference_approximate_matches(V, case, key):
+def test_gpu_reproduces_reference_approximate_matches(V, case, key, wide):
     idx, q = H.load_case(case)
     doedist, k, pct = spec(key)
-    gi = gpu_index(V, case)
+    gi = gpu_index(V, case, wide=wide)   # wide: 64-bit tables on the device
     want = H.expected(case, key)
     # (Hamming distance with wildcards in a read -- bytes are compared, a
     # wildcard equals a wildcard -- and the short-pattern configurations of

@@ -13,14 +13,31 @@ M = H.manifest()
 _gpu_index = {}
 
 
-def gpu_index(V, case, bits=64):
-    key = (case, bits)
+def gpu_index(V, case, bits=64, wide=False):
+    """wide: 64-bit tables ON THE DEVICE whatever the length of the text (what
+    an index of 2^32 symbols and more gets: the uint64_t instantiation of
+    every kernel, the wide form of the deep slots).  The library reads
+    VSA_FORCE_WIDE when an index is created, so the switch is set around the
+    upload only."""
+    key = (case, bits, wide)
     if key not in _gpu_index:
         idx, _ = H.load_case(case)
         i = idx.as_width(bits)
-        _gpu_index[key] = V.Index.from_tables(
-            i.n, i.prefixlength, i.numofchars, i.tis, i.suf, i.lcp, i.llv,
-            i.bck, i.bwt, i.querysepposition, i.hasqueries)
+        before = os.environ.get("VSA_FORCE_WIDE")
+        if wide:
+            os.environ["VSA_FORCE_WIDE"] = "1"
+        try:
+            _gpu_index[key] = V.Index.from_tables(
+                i.n, i.prefixlength, i.numofchars, i.tis, i.suf, i.lcp, i.llv,
+                i.bck, i.bwt, i.querysepposition, i.hasqueries)
+        finally:
+            if wide:
+                if before is None:
+                    del os.environ["VSA_FORCE_WIDE"]
+                else:
+                    os.environ["VSA_FORCE_WIDE"] = before
+        if wide:
+            assert _gpu_index[key].info().device_integersize == 64
     return _gpu_index[key]
 
 
@@ -28,9 +45,9 @@ def gpu_queries(V, q):
     return V.Queries.from_host(q.symbols, q.start, q.length)
 
 
-def run_gpu(V, case, key, bits=64):
+def run_gpu(V, case, key, bits=64, wide=False):
     idx, q = H.load_case(case)
-    gi = gpu_index(V, case, bits)
+    gi = gpu_index(V, case, bits, wide)
     if key.startswith("selfmum"):
         r = V.findmaximaluniquematches(gi, int(key[len("selfmum"):]))
         return H.selfmatches_as_ref(idx, r.fetch())
@@ -74,12 +91,14 @@ CASES = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
          and not k.startswith("approx_")]   # those: tests/test_gpu_approx.py
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])
 @pytest.mark.parametrize("case,key", CASES)
-def test_gpu_reproduces_reference_output(V, case, key):
+def test_gpu_reproduces_reference_output(V, case, key, wide):
     # lists recorded with -qspeedup 0 carry _sp0 in their name, all others come
     # from the reference's default algorithm 2: both are reproduced in order
-    gpu_index(V, case, 64).set_queryspeedup(0 if key.endswith("_sp0") else 2)
-    got = run_gpu(V, case, key)
+    gpu_index(V, case, 64, wide).set_queryspeedup(
+        0 if key.endswith("_sp0") else 2)
+    got = run_gpu(V, case, key, wide=wide)
     want = H.expected(case, key)
     assert len(got) == len(want)
     assert np.array_equal(got, want)

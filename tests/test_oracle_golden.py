@@ -228,3 +228,39 @@ def test_esaapm_restatement_against_the_live_reference():
                         "11", "4"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b"all 4 ok" in p.stdout, p.stdout.decode()
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="needs oracle/_ref (built where "
+                    "/root/reference exists)")
+def test_the_reference_reads_behind_the_text_in_the_approximate_tail(tmp_path):
+    """The one documented deviation of `-complete -e K`:
+    for a start position in the last m + K symbols the reference hands
+    `maxlength` symbols to its longest-match function without looking at the
+    end of the mapped text (Vmengine/approxcompl.c:14-66 ->
+    longestmatch.c:18-71), i.e. it reads what the kernel maps behind the last
+    byte of the .tis file -- zeros ('a') up to the end of the page, anything
+    beyond.  Its answer there is a function of memory the index does not hold:
+    here it reports a match that ENDS BEHIND THE TEXT.  The oracle (and the
+    GPU) end the text where it ends.  scripts/approx_tail_probe.py prints more
+    cases (profiles/r03/approx_tail_reference.txt)."""
+    rng = np.random.default_rng(7)
+    n, m, k = 10000, 40, 2           # n % 4096 != 0: zeros behind the text
+    t = rng.integers(0, 4, n).astype(np.uint8)
+    pat = np.concatenate([t[n - (m - 2):], np.zeros(2, np.uint8)])
+    wd = str(tmp_path)
+    H.write_fasta(wd + "/db.fna", [("s0", t)])
+    H.write_fasta(wd + "/q.fna", [("q0", pat)])
+    H.run_mkvtree_ref(["-db", "db.fna", "-dna", "-pl", "-allout"], wd)
+    rc, lines, _ = H.run_vmatch_ref(["-complete", "-e", str(k), "-q", "q.fna",
+                                     "db.fna"], wd)
+    assert rc == 0 and len(lines) == 1
+    f = lines[0].split()
+    start, length, dist = int(f[2]), int(f[0]), abs(int(f[7]))
+    assert start == n - (m - 2) and start + length > n    # over the end
+    assert (length, dist) == (m, 0)      # "matched" the page's zero padding
+    idx = H.load_mkvtree_index(wd + "/db.fna")
+    got = H.matches_as_ref(idx, H.oracle_approx(idx, H.Queries.from_list([pat]),
+                                                True, k))
+    assert len(got) == 1
+    assert (int(got[0]["dbrel"]), int(got[0]["length"]),
+            int(got[0]["querystart"])) == (start, m - 2, 2)

@@ -1,6 +1,9 @@
 // Handles of the C ABI (include/vstree_amd.h): index upload, query batches,
 // result lists, device utilities.
 #include "vsa_internal.hpp"
+#include <atomic>
+#include <thread>
+#include <time.h>
 #include <algorithm>
 
 static thread_local char g_errbuf[VSA_ERRBUF_SIZE] = "";
@@ -96,50 +99,209 @@ extern "C" int vsa_device_free(void *ptr, int device)
 namespace
 {
 
-// host table with `bits`-wide entries -> device array with `isize`-byte
-// entries; converted through a bounded staging buffer
-int upload_integers(const void *host, uint32_t bits, uint64_t count,
-                    uint32_t isize, void *dev, hipStream_t stream)
+// Host table -> device array, through page-locked staging buffers filled by
+// several host threads at once.  The tables of an index that vmatch has mapped
+// are pageable memory: one hipMemcpy of 12 GB from there is staged by the
+// runtime in ONE thread (3 GB/s here), and the 64-bit suftab of a reference
+// index (include/types.h:41-61) had to be narrowed to 32 bits in one more
+// single-threaded loop first -- 1.9 of the 2.8 s a drop-in run spent before
+// its first search (profiles/r02).  Each worker takes chunks in turn,
+// converts or copies its chunk into its own pinned buffer and sends it on its
+// own stream; the copies of the others run meanwhile.
+//   hostbits / devbytes: width of an entry on either side (8 -> 1 byte for
+//   tis, lcp, bwt; 32 / 64 -> 4 / 8 for suf, bck, llv)
+#define VSA_UPLOAD_CHUNKBYTES (8u << 20)
+#define VSA_UPLOAD_MAXTHREADS 12u
+
+// the page-locked buffers of the workers, made once per index upload (page
+// locking costs about a third of a second per GB)
+struct UploadPool
+{
+  uint8_t *pin[VSA_UPLOAD_MAXTHREADS][2];
+  unsigned int nthreads;
+  UploadPool() : nthreads(0)
+  {
+    memset(pin, 0, sizeof pin);
+  }
+  int init()
+  {
+    unsigned int want = std::thread::hardware_concurrency();
+    if (const char *e = getenv("VSA_UPLOAD_THREADS"))
+    {
+      want = (unsigned int) atoi(e);
+    }
+    want = std::max(1u, std::min(want, VSA_UPLOAD_MAXTHREADS));
+    for (unsigned int t = 0; t < want; t++)
+    {
+      for (int k = 0; k < 2; k++)
+      {
+        if (hipHostMalloc((void **) &pin[t][k], VSA_UPLOAD_CHUNKBYTES,
+                          hipHostMallocDefault) != hipSuccess)
+        {
+          (void) hipGetLastError();
+          pin[t][k] = nullptr;
+          return nthreads > 0 ? 0 : -100; // (fewer workers will do)
+        }
+      }
+      nthreads = t + 1;
+    }
+    return 0;
+  }
+  ~UploadPool()
+  {
+    for (unsigned int t = 0; t < VSA_UPLOAD_MAXTHREADS; t++)
+    {
+      for (int k = 0; k < 2; k++)
+      {
+        if (pin[t][k] != nullptr)
+        {
+          (void) hipHostFree(pin[t][k]);
+        }
+      }
+    }
+  }
+};
+
+int upload_table(UploadPool &pool, const void *host, uint32_t hostbytes,
+                 uint64_t count, uint32_t devbytes, void *dev, int device)
 {
   if (count == 0)
   {
     return 0;
   }
-  if (bits == isize * 8)
-  {
-    VSA_HIP(hipMemcpyAsync(dev, host, count * isize, hipMemcpyHostToDevice,
-                           stream));
-    VSA_HIP(hipStreamSynchronize(stream));
-    return 0;
-  }
-  const uint64_t chunk = 1ull << 24;
-  std::vector<uint8_t> stage(chunk * isize);
-  for (uint64_t done = 0; done < count; done += chunk)
-  {
-    const uint64_t m = std::min(chunk, count - done);
-    if (bits == 64) // 64 -> 32
+  // entries per chunk: the wider side fills the buffer
+  const uint64_t chunk =
+      VSA_UPLOAD_CHUNKBYTES / std::max(hostbytes, devbytes);
+  const uint64_t nchunks = (count + chunk - 1) / chunk;
+  const unsigned int nthreads =
+      (unsigned int) std::min<uint64_t>(pool.nthreads, nchunks);
+  std::atomic<uint64_t> next(0);
+  std::atomic<int> failed(0);
+  auto work = [&](unsigned int me) {
+    if (hipSetDevice(device) != hipSuccess)
     {
-      const uint64_t *src = (const uint64_t *) host + done;
-      uint32_t *dst = (uint32_t *) stage.data();
-      for (uint64_t i = 0; i < m; i++)
+      failed = 1;
+      return;
+    }
+    hipStream_t st = nullptr;
+    uint8_t *pin[2] = {pool.pin[me][0], pool.pin[me][1]};
+    hipEvent_t sent[2] = {nullptr, nullptr};
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++)
+    {
+      ok = hipEventCreateWithFlags(&sent[k], hipEventDisableTiming) ==
+           hipSuccess;
+    }
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (ok && failed == 0)
+    {
+      const uint64_t c = next.fetch_add(1);
+      if (c >= nchunks)
       {
-        dst[i] = (uint32_t) src[i];
+        break;
       }
-    } else // 32 -> 64
-    {
-      const uint32_t *src = (const uint32_t *) host + done;
-      uint64_t *dst = (uint64_t *) stage.data();
-      for (uint64_t i = 0; i < m; i++)
+      const uint64_t first = c * chunk, m = std::min(chunk, count - first);
+      if (used[slot] && hipEventSynchronize(sent[slot]) != hipSuccess)
       {
-        dst[i] = src[i];
+        ok = false;
+        break;
+      }
+      if (hostbytes == devbytes)
+      {
+        memcpy(pin[slot], (const uint8_t *) host + first * hostbytes,
+               m * hostbytes);
+      } else if (hostbytes == 8) // 64 -> 32
+      {
+        const uint64_t *src = (const uint64_t *) host + first;
+        uint32_t *dst = (uint32_t *) pin[slot];
+        for (uint64_t i = 0; i < m; i++)
+        {
+          dst[i] = (uint32_t) src[i];
+        }
+      } else // 32 -> 64
+      {
+        const uint32_t *src = (const uint32_t *) host + first;
+        uint64_t *dst = (uint64_t *) pin[slot];
+        for (uint64_t i = 0; i < m; i++)
+        {
+          dst[i] = src[i];
+        }
+      }
+      ok = hipMemcpyAsync((uint8_t *) dev + first * devbytes, pin[slot],
+                          m * devbytes, hipMemcpyHostToDevice, st) ==
+               hipSuccess &&
+           hipEventRecord(sent[slot], st) == hipSuccess;
+      used[slot] = true;
+      slot ^= 1;
+    }
+    if (st != nullptr && hipStreamSynchronize(st) != hipSuccess)
+    {
+      ok = false;
+    }
+    for (int k = 0; k < 2; k++)
+    {
+      if (sent[k] != nullptr)
+      {
+        (void) hipEventDestroy(sent[k]);
       }
     }
-    VSA_HIP(hipMemcpyAsync((uint8_t *) dev + done * isize, stage.data(),
-                           m * isize, hipMemcpyHostToDevice, stream));
-    VSA_HIP(hipStreamSynchronize(stream));
+    if (st != nullptr)
+    {
+      (void) hipStreamDestroy(st);
+    }
+    if (!ok)
+    {
+      (void) hipGetLastError();
+      failed = 1;
+    }
+  };
+  std::vector<std::thread> threads;
+  for (unsigned int t = 1; t < nthreads; t++)
+  {
+    threads.emplace_back(work, t);
+  }
+  work(0);
+  for (std::thread &t : threads)
+  {
+    t.join();
+  }
+  if (failed != 0)
+  {
+    VSA_ERROR("upload of an index table failed");
+    return -100;
   }
   return 0;
 }
+
+
+// VSA_TRACE=1: where the time of an index upload goes (stderr)
+struct UploadTrace
+{
+  double t0;
+  bool on;
+  UploadTrace()
+  {
+    const char *e = getenv("VSA_TRACE");
+    on = e != nullptr && strcmp(e, "0") != 0;
+    t0 = now();
+  }
+  static double now()
+  {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+  }
+  void step(const char *what)
+  {
+    if (on)
+    {
+      const double t = now();
+      fprintf(stderr, "vstree_amd: upload: %-28s %.3f s\n", what, t - t0);
+      t0 = t;
+    }
+  }
+};
 
 uint64_t powu64(uint64_t b, uint32_t e)
 {
@@ -451,45 +613,37 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
     vsa_index_close(ix);
     return code;
   };
-  if (n > 0 && t->tis != nullptr &&
-      hipMemcpyAsync(ix->tis_alloc + VSA_TIS_FRONTPAD, t->tis, n,
-                     hipMemcpyHostToDevice, s) != hipSuccess)
+  UploadTrace tr;
+  UploadPool pool;
+  // (the workers' streams are their own: what is queued on the index's stream
+  // -- the padding around the text -- is waited for first)
+  if (pool.init() != 0 || hipStreamSynchronize(s) != hipSuccess ||
+      (n > 0 && t->tis != nullptr &&
+       upload_table(pool, t->tis, 1, n, 1, ix->tis_alloc + VSA_TIS_FRONTPAD,
+                    device)) ||
+      upload_table(pool, t->lcp, 1, n + 1, 1, ix->lcp, device) ||
+      (t->bwt != nullptr &&
+       upload_table(pool, t->bwt, 1, n + 1, 1, ix->bwt, device)))
   {
-    VSA_ERROR("upload of tis failed");
+    VSA_ERROR("upload of the text tables failed");
     return fail(-100);
   }
-  if (hipMemcpyAsync(ix->lcp, t->lcp, n + 1, hipMemcpyHostToDevice, s) !=
-      hipSuccess)
-  {
-    VSA_ERROR("upload of lcp failed");
-    return fail(-100);
-  }
-  if (t->bwt != nullptr &&
-      hipMemcpyAsync(ix->bwt, t->bwt, n + 1, hipMemcpyHostToDevice, s) !=
-          hipSuccess)
-  {
-    VSA_ERROR("upload of bwt failed");
-    return fail(-100);
-  }
-  if (hipStreamSynchronize(s) != hipSuccess)
-  {
-    VSA_ERROR("upload failed");
-    return fail(-100);
-  }
+  tr.step("tis, lcp, bwt");
   if (t->bck == nullptr)
   {
     (void) hipFree(ix->bck);
     ix->bck = nullptr;
   }
-  if (upload_integers(t->suf, t->integersize, n + 1, ix->isize, ix->suf, s) ||
+  const uint32_t hb = t->integersize / 8;
+  if (upload_table(pool, t->suf, hb, n + 1, ix->isize, ix->suf, device) ||
       (t->bck != nullptr &&
-       upload_integers(t->bck, t->integersize, 2 * ix->numofcodes, ix->isize,
-                       ix->bck, s)) ||
-      upload_integers(t->llv, t->integersize, 2 * ix->nllv, ix->isize,
-                      ix->llv, s))
+       upload_table(pool, t->bck, hb, 2 * ix->numofcodes, ix->isize, ix->bck,
+                    device)) ||
+      upload_table(pool, t->llv, hb, 2 * ix->nllv, ix->isize, ix->llv, device))
   {
     return fail(-100);
   }
+  tr.step("suf, bck, llv");
   {
     unsigned int bad = 0;
     if (ix->isize == 4 ? validate_tables<uint32_t>(ix, &bad)
@@ -508,10 +662,12 @@ extern "C" int vsa_index_from_tables(const vsa_tables *t, int device,
       return fail(-2);
     }
   }
+  tr.step("validation");
   if (t->bck != nullptr && vsa_index_make_esa8(ix) != 0)
   {
     return fail(-100);
   }
+  tr.step("derived search tables");
   *index = ix;
   return 0;
 }

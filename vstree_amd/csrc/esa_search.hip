@@ -2123,6 +2123,25 @@ int vsa_index_make_esa8(vsa_index *ix)
   if (fd != nullptr && atoi(fd) >= (int) ix->pl && atoi(fd) <= 16)
   {
     D = (uint32_t) atoi(fd);
+  } else
+  {
+    // one symbol less where the device has not room for the slot table, the
+    // bucket bounds it is made from, the keyed array and a tenth of the
+    // device for the searches themselves: half the index for a fifth more
+    // time per batch (profiles/r03/footprint_deep_prefix.txt)
+    size_t freeb = 0, totalb = 0;
+    while (D > ix->pl && D > 12 &&
+           hipMemGetInfo(&freeb, &totalb) == hipSuccess)
+    {
+      const uint64_t codes = 1ull << (2 * D),
+                     need = 16 * codes + 2 * codes * ix->isize +
+                            8 * (ix->n + 1) + ix->n / 4 + totalb / 10;
+      if (need <= freeb)
+      {
+        break;
+      }
+      D--;
+    }
   }
   if (D > 16)
   {
