@@ -53,6 +53,29 @@ def world(V):
                                             NQ, M, dq, 0))
     queries = V.Queries.from_device(dq, NQ, M)
     V.device_free(dq)
+    # repeats for the family of the index itself (maximal / supermaximal /
+    # tandem repeats), planted behind the reads were cut, in stretches no read
+    # touches: a copy of 300 symbols and an array of six 25-symbol units in
+    # the upper part of the text (beyond 2^32 for the full-size run)
+    spos = np.sort(pos)
+
+    def free_stretch(near, length):
+        k = int(np.searchsorted(spos, near))
+        while k + 1 < len(spos) and \
+                int(spos[k + 1]) - (int(spos[k]) + M) < length + 8:
+            k += 1
+        return int(spos[k]) + M + 4
+
+    rng = np.random.default_rng(99)
+    hi = max(N - N // 40, min(N - 10 ** 6, (1 << 32) + 10 ** 6))
+    src, dst = free_stretch(N // 3, 300), free_stretch(hi, 300)
+    tan = free_stretch(dst + 10 ** 5, 150)
+    assert sep < dst < tan < N - 1000
+    piece = np.zeros(300, np.uint8)
+    V.device_download(piece, C.c_void_p(dg.value + src))
+    V.device_upload(C.c_void_p(dg.value + dst), piece)
+    unit = rng.integers(0, 4, 25).astype(np.uint8)
+    V.device_upload(C.c_void_p(dg.value + tan), np.tile(unit, 6))
     index = V.Index.build_device(dg, N, 4, 0)
     V.device_free(dg)
     t = index.download()
@@ -60,7 +83,7 @@ def world(V):
     host = H.Index(N, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
                    t["llv"], t["bck"], t["bwt"], None)
     yield dict(index=index, queries=queries, host=host, pos=pos, sub=sub,
-               step=step, info=info, sep=sep)
+               step=step, info=info, sep=sep, planted=(src, dst, tan))
     index.close()
     V.lib.vsa_device_trim(0)
 
@@ -70,7 +93,9 @@ def test_the_tables_are_wide_and_have_the_deep_form(world):
     assert info.totallength == N
     if N + 1 >= 1 << 32:
         assert info.device_integersize == 64
-    assert info.deepprefix == 16
+    # (16 = ceil(log4 n), one less where the device lacks room for the slot
+    # table and its construction: vsa_index_make_esa8)
+    assert info.deepprefix in (15, 16)
     assert info.prefixlength == H.recommended_prefixlength(4, N)
     assert world["host"].suf.dtype == (np.uint64 if N + 1 >= 1 << 32
                                        else np.uint32)
@@ -137,6 +162,30 @@ def test_planted_answers_and_global_mum_filter(V, world):
         assert np.array_equal(tis[s:s + ln], hq[qo:qo + ln])
         assert qo + ln == M or s + ln == N or tis[s + ln] != hq[qo + ln]
         assert qo == 0 or s == 0 or tis[s - 1] != hq[qo - 1]
+
+
+def test_repeats_of_the_index_itself_beyond_2_32(V, world):
+    """vmatch -l / -supermax / -tandem on the index itself with suffix array
+    positions and text positions beyond 2^32 (the 64-bit position
+    instantiation of selfmatch_search.inc): the planted copy and the planted
+    array come back, in the reference's order, as the oracle finds them on
+    the same tables (include/vdfstrav.c:247, Vmengine/fsuper.c:142,
+    ftandem.c:261 know no 32-bit limit either)"""
+    ix, host = world["index"], world["host"]
+    src, dst, tan = world["planted"]
+    got = V.findmaximalrepeats(ix, 40).fetch()
+    assert np.array_equal(got, H.oracle_repeats(host, 40))
+    assert any(int(r["dbstart"]) == src and int(r["queryseq"]) == dst and
+               int(r["length"]) >= 300 for r in got)
+    got = V.findsupermaximalrepeats(ix, 40).fetch()
+    assert np.array_equal(got, H.oracle_supermax(host, 40))
+    assert len(got) >= 1
+    got = V.findtandems(ix, 20).fetch()
+    assert np.array_equal(got, H.oracle_tandems(host, 20))
+    assert len(got) >= 4 and (got["dbstart"] >= tan).all() and \
+        (got["dbstart"] < tan + 150).all()
+    if N + 1 >= 1 << 32:
+        assert dst >= 1 << 32 and tan >= 1 << 32
 
 
 def test_self_index_scan_on_the_wide_index(V, world):

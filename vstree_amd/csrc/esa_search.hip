@@ -2130,6 +2130,8 @@ int vsa_index_make_esa8(vsa_index *ix)
     // device for the searches themselves: half the index for a fifth more
     // time per batch (profiles/r03/footprint_deep_prefix.txt)
     size_t freeb = 0, totalb = 0;
+    (void) hipStreamSynchronize(ix->stream);
+    vsa_dev_trim(); // (what the builder's temporaries held counts as free)
     while (D > ix->pl && D > 12 &&
            hipMemGetInfo(&freeb, &totalb) == hipSuccess)
     {
@@ -3080,8 +3082,8 @@ extern "C" int vsa_findmaximalrepeats(const vsa_index *index,
   }
   vsa_result *res = newresult(index->device);
   const int rc = (index->isize == 4)
-                     ? run_repeats<uint32_t>(index, searchlength, res)
-                     : run_repeats<uint64_t>(index, searchlength, res);
+                     ? run_repeats<uint32_t, uint32_t>(index, searchlength, res)
+                     : run_repeats<uint64_t, uint64_t>(index, searchlength, res);
   if (rc != 0)
   {
     vsa_result_free(res);
@@ -3125,8 +3127,8 @@ extern "C" int vsa_findsupermaximalrepeats(const vsa_index *index,
   }
   vsa_result *res = newresult(index->device);
   const int rc = (index->isize == 4)
-                     ? run_supermax<uint32_t>(index, searchlength, res)
-                     : run_supermax<uint64_t>(index, searchlength, res);
+                     ? run_supermax<uint32_t, uint32_t>(index, searchlength, res)
+                     : run_supermax<uint64_t, uint64_t>(index, searchlength, res);
   if (rc != 0)
   {
     vsa_result_free(res);
@@ -3168,8 +3170,8 @@ extern "C" int vsa_findtandems(const vsa_index *index, uint64_t searchlength,
   }
   vsa_result *res = newresult(index->device);
   const int rc = (index->isize == 4)
-                     ? run_tandems<uint32_t>(index, searchlength, res)
-                     : run_tandems<uint64_t>(index, searchlength, res);
+                     ? run_tandems<uint32_t, uint32_t>(index, searchlength, res)
+                     : run_tandems<uint64_t, uint64_t>(index, searchlength, res);
   if (rc != 0)
   {
     vsa_result_free(res);

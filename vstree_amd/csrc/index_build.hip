@@ -383,8 +383,16 @@ k_bck_boundaries(const uint8_t *__restrict__ tis, uint64_t n,
   }
   bool cut, prevcut = false;
   const uint64_t code = vb_padcode(tis, sa[j], pl, numofchars, cut);
-  uint64_t prevcode = 0;
-  if (j > 0)
+  // the code of suffix j - 1 is what the lane below has just computed (a
+  // second look at the text for it -- a random read per suffix -- was half of
+  // this kernel's time: 0.7 s of a drop-in run's start at 3 Gbp); the first
+  // lane of a wavefront computes it itself
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t prevcode = ((uint64_t) (uint32_t) __shfl_up((int) (code >> 32), 1, 64)
+                       << 32) |
+                      (uint32_t) __shfl_up((int) (uint32_t) code, 1, 64);
+  prevcut = __shfl_up(cut ? 1 : 0, 1, 64) != 0;
+  if (lane == 0 && j > 0)
   {
     prevcode = vb_padcode(tis, sa[j - 1], pl, numofchars, prevcut);
   }
