@@ -182,7 +182,8 @@ def test_repeats_of_the_index_itself_beyond_2_32(V, world):
     assert len(got) >= 1
     got = V.findtandems(ix, 20).fetch()
     assert np.array_equal(got, H.oracle_tandems(host, 20))
-    assert len(got) >= 4 and (got["dbstart"] >= tan).all() and \
+    # (u^6: the right branching repeats with units of 75, 50 and 25 symbols)
+    assert len(got) >= 3 and (got["dbstart"] >= tan).all() and \
         (got["dbstart"] < tan + 150).all()
     if N + 1 >= 1 << 32:
         assert dst >= 1 << 32 and tan >= 1 << 32
