@@ -26,36 +26,46 @@ def main():
     traffic = sys.argv[4] if len(sys.argv) > 4 else None
     sums = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
-    # passes that ran two steps (pmc_passes.sh, "2 COUNTER"): only for the
-    # traffic of one whole step = totals(two steps) - totals(one step)
-    two = collections.defaultdict(lambda: collections.defaultdict(float))
+    # The traffic of ONE whole step: in the passes with one step, everything
+    # between the first k_mum_first launch and the next one (the untimed call
+    # that dumps the plans for bench.py's byte count) in dispatch order.
+    # (Passes that ran two steps -- pmc_passes.sh, "2 COUNTER" -- were meant for
+    # a difference of totals; the builder's kernels move 100 times the bytes of
+    # a step and their run-to-run noise drowned it: not used.)
+    step = collections.defaultdict(float)
     for f in sorted(glob.glob(d + "/p*/*/*counter_collection.csv")):
         pdir = f[len(d) + 1:].split("/")[0]
         marker = os.path.join(d, pdir + ".steps")
         steps = int(open(marker).read()) if os.path.exists(marker) else 1
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        if steps == 2:
+            continue
+        for r in rows:
             k = short(r["Kernel_Name"])
-            if steps == 2:
-                two[k][r["Counter_Name"]] += float(r["Counter_Value"])
-                continue
             sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[k][r["Counter_Name"]] += 1
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        firsts = [i for i, r in enumerate(rows)
+                  if "k_mum_first" in r["Kernel_Name"]]
+        ids = sorted({int(rows[i]["Dispatch_Id"]) for i in firsts})
+        if len(ids) >= 2:
+            for r in rows:
+                if ids[0] <= int(r["Dispatch_Id"]) < ids[1] and \
+                        r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    step[(short(r["Kernel_Name"]), r["Counter_Name"])] += \
+                        float(r["Counter_Value"])
     step_bytes = None
-    if two:
+    if step:
         # FETCH_SIZE counts wide coalesced reads at half their size on gfx950
         # (MI355X_MICROARCH.md): doubled for every kernel but the searches,
         # whose reads are random 8/16-byte words, one 64-byte request each
         random = ("k_mum_first", "k_mum_plan", "k_query_search",
                   "k_complete_search", "k_mum_anchor")
-        step_bytes, per_kernel = 0.0, {}
-        for k in two:
-            f2 = two[k].get("FETCH_SIZE", 0.0) - sums[k].get("FETCH_SIZE", 0.0)
-            w2 = two[k].get("WRITE_SIZE", 0.0) - sums[k].get("WRITE_SIZE", 0.0)
-            fac = 1 if k.startswith(random) else 2
-            b = (max(f2, 0.0) * fac + max(w2, 0.0)) * 1024
-            if b > 0:
-                per_kernel[k] = b
-            step_bytes += b
+        step_bytes, per_kernel = 0.0, collections.defaultdict(float)
+        for (k, c), v in step.items():
+            fac = 2 if (c == "FETCH_SIZE" and not k.startswith(random)) else 1
+            per_kernel[k] += v * fac * 1024
+            step_bytes += v * fac * 1024
     counters = sorted({c for k in sums for c in sums[k]})
     want = [k for k in sums if k.startswith("k_") or "k_" in k]
     lines = ["rocprofv3 --pmc, one pass per counter group (scripts/"

@@ -1019,7 +1019,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   tall.start();
   // MUM modes over batches of equal-length queries: anchor pass + work list
   DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wfirste,
-      wfmlen, wfmdb, wfslot;
+      wfmlen, wfmdb, wboffset;
+  uint64_t nfirstpass = 0; // candidates of the first pass (k_append_first)
   uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
   // -mum with the filter: candidates as (sort key, value) pairs, see
   // mumfilter_packed
@@ -1172,35 +1173,42 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         // (queries < 2^32: the condition of this branch)
         const uint64_t nb = blocksfor(nq), nbr = vsa_grid_blocks(nb);
         const uint32_t threshold = wanted.threshold;
-        DevBuf bcount, boffset;
-        if (bcount.alloc((nbr + 1) * 4) || boffset.alloc((nbr + 1) * 4))
+        DevBuf bcount;
+        if (bcount.alloc((nbr + 1) * 8) || wboffset.alloc((nbr + 1) * 8))
         {
           return -100;
         }
+        // (both halves of a count stay below 2^32: nq does)
+        VSA_HIP(hipMemsetAsync(bcount.as<uint64_t>() + nb, 0, 8, stream));
         k_wanted_count<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
-            wcount.as<uint32_t>(), nq, threshold, bcount.as<uint32_t>());
+            wcount.as<uint32_t>(), nq, threshold,
+            firstpass ? wfmlen.as<uint32_t>() : nullptr,
+            bcount.as<uint64_t>());
         VSA_HIP(hipGetLastError());
-        VSA_HIP(rocprim::exclusive_scan(nullptr, tb, bcount.as<uint32_t>(),
-                                        boffset.as<uint32_t>(), (uint32_t) 0,
+        VSA_HIP(rocprim::exclusive_scan(nullptr, tb, bcount.as<uint64_t>(),
+                                        wboffset.as<uint64_t>(), (uint64_t) 0,
                                         (size_t) (nb + 1),
-                                        rocprim::plus<uint32_t>(), stream));
+                                        rocprim::plus<uint64_t>(), stream));
         if (wtemp.alloc(tb))
         {
           return -100;
         }
-        VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, bcount.as<uint32_t>(),
-                                        boffset.as<uint32_t>(), (uint32_t) 0,
+        VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, bcount.as<uint64_t>(),
+                                        wboffset.as<uint64_t>(), (uint64_t) 0,
                                         (size_t) (nb + 1),
-                                        rocprim::plus<uint32_t>(), stream));
+                                        rocprim::plus<uint64_t>(), stream));
         k_wanted_fill<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
-            wcount.as<uint32_t>(), nq, threshold, boffset.as<uint32_t>(),
+            wcount.as<uint32_t>(), nq, threshold, wboffset.as<uint64_t>(),
             wlist.as<uint32_t>());
         VSA_HIP(hipGetLastError());
-        const Fetch f = {boffset.as<uint32_t>() + nb, 4};
-        if (fetchwords(stream, &f, 1, &nlist))
+        const Fetch f = {wboffset.as<uint64_t>() + nb, 8};
+        uint64_t both = 0;
+        if (fetchwords(stream, &f, 1, &both))
         {
           return -100;
         }
+        nlist = both & 0xFFFFFFFFull;
+        nfirstpass = both >> 32;
       }
       if (nlist > 0)
       {
@@ -1392,29 +1400,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   {
     return -100;
   }
-  if (firstpass)
-  {
-    // slots of the first-pass candidates behind the kernel's matches:
-    // enqueued ahead of the search so that one read-back serves both
-    const uint64_t nq = queries->nq;
-    size_t tb = 0;
-    auto flag = rocprim::make_transform_iterator(wfmlen.as<uint32_t>(),
-                                                 NonZeroToU32());
-    if (wfslot.alloc(nq * 4))
-    {
-      return -100;
-    }
-    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, flag, wfslot.as<uint32_t>(),
-                                    (uint32_t) 0, (size_t) nq,
-                                    rocprim::plus<uint32_t>(), stream));
-    if (wtemp.alloc(tb))
-    {
-      return -100;
-    }
-    VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, flag, wfslot.as<uint32_t>(),
-                                    (uint32_t) 0, (size_t) nq,
-                                    rocprim::plus<uint32_t>(), stream));
-  }
   // first guess: MUM modes report at most one match per work-item but
   // typically about one per query; MEM is unbounded.  The kernel counts what
   // it needs and never writes past a region's capacity; on overflow of any
@@ -1598,8 +1583,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     // where each region goes in the dense list, how much there is
     k_shard_summary<<<1, 1024, 0, stream>>>(
         cursor.as<unsigned long long>(), nshards, doff.as<uint64_t>(),
-        firstpass ? wfslot.as<uint32_t>() + queries->nq - 1 : nullptr,
-        firstpass ? wfmlen.as<uint32_t>() + queries->nq - 1 : nullptr,
+        nullptr, nullptr,
         summary.as<uint64_t>());
     VSA_HIP(hipGetLastError());
     {
@@ -1617,7 +1601,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       nplan = planemit ? got[5] : 0;
       needed = got[0];
       maxshard = got[1];
-      nfirst = firstpass ? got[2] + (got[3] != 0 ? 1 : 0) : 0;
+      nfirst = firstpass ? nfirstpass : 0;
       plannedwork = fromplan ? got[4] : 0;
     }
     searchms += tsearch.ms();
@@ -1688,7 +1672,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     {
       k_append_first<<<gridfor(queries->nq), VSA_BLOCK, 0, stream>>>(
           wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
-          wfslot.as<uint32_t>(), queries->nq, perquery, dbase, qs.seqoffset,
+          wboffset.as<uint64_t>(), queries->nq, perquery, dbase, qs.seqoffset,
           needed + nplan,
           out.as<vsa_match>(), keys.as<uint64_t>(), packbits, valbits);
       VSA_HIP(hipGetLastError());
