@@ -833,6 +833,8 @@ def main():
                 a, V, H, index, host, qsym, m, L, dev, qps,
                 free_index=lambda: index.close())
         if extras:
+            index.close()   # (if the CPU baselines have not done so: room for
+            #                  the second 3 Gbp index)
             k3 = selfmum_family(a, V, n, L, dev)
             fams.append(k3)
             # north_star's "suftab scan": where the driver's record keeps it
