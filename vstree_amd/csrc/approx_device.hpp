@@ -11,7 +11,7 @@
 
 #include "esa_device.hpp"
 
-#define VSA_APM_MAXWORDS 4 // patterns up to 256 symbols
+#define VSA_APM_MAXWORDS 8 // patterns up to 512 symbols (round 3; 4 words before)
 
 // Column state of one pattern: the vertical +1 / -1 vectors of Myers'
 // algorithm and the Eq masks of a 4-letter alphabet.  W words.
