@@ -50,7 +50,7 @@ def test_gpu_reproduces_reference_approximate_matches(V, case, key, wide):
                                  (200, 5), (250, 3), (120, 4), (90, 3),
                                  # beyond 256 symbols: five to eight 64-bit
                                  # words per Myers column (round 3)
-                                 (300, 3), (400, 6), (512, 4)])
+                                 (300, 3), (400, 6), (500, 4)])
 def test_gpu_equals_oracle_on_repeats_and_separators(V, doedist, qwild, m, k):
     """texts with diverged repeats (many overlapping regions), several
     sequences (separators inside regions) and wildcards; reads with up to
