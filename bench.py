@@ -595,7 +595,10 @@ def main():
         first_ms.append(s.first_kernel_ms)
         mine = torch.empty(max(r.count, 1) * 2, dtype=torch.int64,
                            device="cuda")[:r.count * 2]
-        send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()))
+        # (the rows for this rank's own range behind the others: they stay
+        # where they are, the exchange runs over the rows in front of them)
+        send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()),
+                                own=rank)
         r.close()
         cdev = "cuda"
         if a.rehearse_on_one_gpu:
@@ -603,11 +606,13 @@ def main():
 
         # phase 2: the one exchange step (RCCL all-to-all) -- every rank runs
         # the uniqueness filter on its range with the carry of the lower ones
-        def filter_fn(part, carry):
-            part = part.cuda().contiguous()
-            res = V.mumuniqueinquery_range_packed(
-                C.c_void_p(part.data_ptr()), part.numel() // 2, lenbits, n,
-                carry, dev)
+        def filter_fn(own, received, carry):
+            own = own.cuda().contiguous()
+            received = received.cuda().contiguous()
+            res = V.mumuniqueinquery_range_packed2(
+                C.c_void_p(own.data_ptr()), own.numel() // 2,
+                C.c_void_p(received.data_ptr()), received.numel() // 2,
+                lenbits, n, carry, dev)
             st = res.stats()
             res.close()
             return st.count, st.sumlength
@@ -616,7 +621,8 @@ def main():
         nmum, sumlen, ncand, searches, ksearches = \
             S.partitioned_mum_filter_presorted(
                 dist, torch, mine, send, top, cdev, filter_fn, words=2,
-                extra=[s.searches, s.kernel_searches], reduce=False)
+                extra=[s.searches, s.kernel_searches], reduce=False,
+                own_last=True)
         totals = (nmum, sumlen, searches, ncand, ksearches)
 
     for _ in range(a.warmup):

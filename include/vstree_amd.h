@@ -301,6 +301,15 @@ uint32_t vsa_result_packbits(const vsa_result *result);
 int vsa_result_partition(const vsa_result *result, uint32_t nparts,
                          uint64_t totallength, void *device_matches,
                          uint64_t *counts, uint64_t *maxright);
+/* ... with the part `ownpart` (0 .. nparts-1) written behind all others, the
+   others in ascending order in front of it: a rank's own candidates stay
+   where they are, the rows in front of them are the send buffer of an
+   all-to-all whose split for the rank itself is 0.  counts and maxright are
+   indexed by part as above.  ownpart < 0: vsa_result_partition. */
+int vsa_result_partition_own(const vsa_result *result, uint32_t nparts,
+                             int ownpart, uint64_t totallength,
+                             void *device_matches, uint64_t *counts,
+                             uint64_t *maxright);
 
 /*
   findcompletematches for approximate matching on the index, vmatch
@@ -452,6 +461,14 @@ int vsa_mumuniqueinquery_range_packed(const void *device_rows, uint64_t nrows,
                                       uint64_t totallength, int device,
                                       uint64_t carry_dbright,
                                       vsa_result **result);
+/* ... on two lists of such rows taken as one (a rank's own rows, which need
+   not travel through the exchange, and the rows it received) */
+int vsa_mumuniqueinquery_range_packed2(const void *device_rows, uint64_t nrows,
+                                       const void *more_rows, uint64_t nmore,
+                                       uint32_t lengthbits,
+                                       uint64_t totallength, int device,
+                                       uint64_t carry_dbright,
+                                       vsa_result **result);
 
 /*
   The same three entry points with the reference's delivery model: every

@@ -123,12 +123,63 @@ def test_pieces_with_a_threshold_of_their_own(V):
     tiny = H.Queries.from_list([q.symbols[:20], q.symbols[160:180]])
     got = V.findapproxcompletematches(gi, gpu_queries(V, tiny), True, 3)
     assert np.array_equal(got.fetch(), H.oracle_approx(idx, tiny, True, 3))
-    # what neither path takes is still declined before any work: a batch that
-    # mixes threshold 0 (2 % of 20 symbols) with thresholds > 0
+    # a batch that mixes threshold 0 (2 % of 20 symbols) with thresholds > 0
+    # (declined until round 3): the exact search for the first read,
+    # splitesaapm for the second (approxcompl.c:167-191)
     mixed = H.Queries.from_list([q.symbols[:20], q.symbols[150:300]])
+    got = V.findapproxcompletematches(gi, gpu_queries(V, mixed), True, 2, True)
+    assert np.array_equal(got.fetch(),
+                          H.oracle_approx(idx, mixed, True, 2, True))
+
+
+@pytest.mark.parametrize("doedist", [True, False], ids=["edit", "hamming"])
+@pytest.mark.parametrize("pct", [1, 2, 3])
+def test_thresholds_zero_and_above_in_one_batch(V, doedist, pct):
+    """-e Kp / -h Kp over reads of 12 ... 260 symbols: the short ones have
+    threshold 0 and are exact searches, the others go through the pigeonhole
+    or the tree path; the list is the oracle's, read by read"""
+    idx, q = H.load_case("c5")
+    gi = gpu_index(V, "c5")
+    rng = np.random.default_rng(77 + pct)
+    text = idx.tis[:idx.n]
+    qs = []
+    for i in range(400):
+        m = int(rng.integers(12, 261))
+        p = int(rng.integers(0, idx.n - m))
+        r = text[p:p + m].copy()
+        r[r >= 254] = rng.integers(0, 4)
+        for e in range(int(rng.integers(0, 3))):
+            x = int(rng.integers(0, m))
+            r[x] = (r[x] + 1 + rng.integers(0, 3)) % 4
+        qs.append(r.astype(np.uint8))
+    mixed = H.Queries.from_list(qs)
+    ks = mixed.length * pct // 100
+    assert (ks == 0).sum() > 20 and (ks > 0).sum() > 20
+    want = H.oracle_approx(idx, mixed, doedist, pct, True)
+    got = V.findapproxcompletematches(gi, gpu_queries(V, mixed), doedist, pct,
+                                      True)
+    assert len(want) > 200 and np.array_equal(got.fetch(), want)
+    st = got.stats()
+    assert st.count == len(want) and st.sumlength == int(want["length"].sum())
+
+
+def test_mixed_thresholds_stop_at_the_reference_errors(V):
+    """the first read shorter than prefixlength (threshold 0: the exact
+    search's error, exactcompl.c:179-185) ends the run; the reads before it
+    are answered"""
+    idx, q = H.load_case("c5")
+    gi = gpu_index(V, "c5")
+    reads = [q.symbols[:150], q.symbols[160:180], q.symbols[200:203],
+             q.symbols[400:550]]
+    mixed = H.Queries.from_list(reads)
+    with pytest.raises(H.OracleError) as oe:
+        H.oracle_approx(idx, mixed, True, 2, True)
     with pytest.raises(V.VsaError) as ei:
         V.findapproxcompletematches(gi, gpu_queries(V, mixed), True, 2, True)
-    assert ei.value.code == V.NOT_COVERED and ei.value.partial is None
+    assert "patternlength=3 must be >=" in str(ei.value)
+    assert str(oe.value) in str(ei.value)
+    assert np.array_equal(ei.value.partial.fetch(), oe.value.partial)
+    assert len(oe.value.partial) >= 1
 
 
 def test_threshold_zero_is_the_exact_search(V):

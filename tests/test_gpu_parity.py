@@ -870,12 +870,46 @@ def test_packed_candidates_and_filter_in_ranges(V):
         assert used == (bits or 7) and r.rowwords == 2
         assert np.array_equal(H.sorted_matches(r.fetch()),
                               H.sorted_matches(cand))
-        for world in (1, 3):
+        # (up to 8 parts: tiles of 2 048 pairs counted in registers; beyond:
+        # the general kernels; own: that part behind all others)
+        for world, own in ((1, -1), (3, -1), (2, 0), (8, 5), (8, 7), (9, 4),
+                           (1, 0)):
             dp = V.device_malloc(max(r.count * 16, 16))
-            counts, top = r.partition(world, idx.n, dp)
+            counts, top = r.partition(world, idx.n, dp, own=own)
             rows = np.zeros((r.count, 2), np.uint64)
             V.device_download(rows, dp)
             assert int(counts.sum()) == r.count
+            if own >= 0:
+                # the layout: others ascending, the own part last; the two
+                # lists of the own-last form give the filter's answer for
+                # that range
+                order = [p for p in range(world) if p != own] + [own]
+                got = S.unpack_candidates(rows, used, V.MATCH_DTYPE)
+                dest = (got["dbstart"] * np.uint64(world)) // np.uint64(
+                    idx.n + 1)
+                assert np.array_equal(
+                    dest, np.repeat(np.array(order, np.uint64),
+                                    counts[order].astype(np.int64)))
+                nown = int(counts[own])
+                whole = S.unpack_candidates(rows[r.count - nown:], used,
+                                            V.MATCH_DTYPE)
+                cut = nown // 3
+                res = V.mumuniqueinquery_range_packed2(
+                    C.c_void_p(dp.value + 16 * (r.count - nown)), cut,
+                    C.c_void_p(dp.value + 16 * (r.count - nown + cut)),
+                    nown - cut, used, idx.n, 0)
+                one = V.mumuniqueinquery_range_packed(
+                    C.c_void_p(dp.value + 16 * (r.count - nown)), nown, used,
+                    idx.n, 0)
+                assert np.array_equal(res.fetch(), one.fetch())
+                assert np.array_equal(one.fetch(),
+                                      H.oracle_mumfilter(whole, 0))
+                # back to part order for the checks below
+                back = np.concatenate(
+                    [rows[:int(counts[:own].sum())], rows[r.count - nown:],
+                     rows[int(counts[:own].sum()):r.count - nown]])
+                V.device_upload(dp, back)
+                rows = back
             assert np.array_equal(
                 H.sorted_matches(S.unpack_candidates(rows, used,
                                                      V.MATCH_DTYPE)),

@@ -189,6 +189,93 @@ def test_repeats_of_the_index_itself_beyond_2_32(V, world):
         assert dst >= 1 << 32 and tan >= 1 << 32
 
 
+def test_approximate_matches_beyond_2_32(V, world):
+    """vmatch -complete -e 2 / -h 2 with text positions beyond 2^32 (the
+    pigeonhole path with its positions and sort keys in the width of the
+    tables): 2 000 reads, most of them cut from the upper end of the text,
+    against the oracle on the same tables (Vmengine/splitesaapm.c:458-558
+    knows no 32-bit limit either)"""
+    order = np.argsort(world["pos"], kind="stable")
+    sel = np.unique(np.concatenate([order[-1500:],
+                                    order[::max(1, NQ // 500)][:500]]))
+    hq = F.host_queries(world, sel)
+    gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
+    ix, host = world["index"], world["host"]
+    for doedist in (True, False):
+        got = V.findapproxcompletematches(ix, gq, doedist, 2).fetch()
+        want = H.oracle_approx(host, hq, doedist, 2)
+        assert len(want) >= len(sel) // 2
+        assert np.array_equal(got, want), doedist
+        if N + 1 >= 1 << 32:
+            assert (got["dbstart"] >= 1 << 32).sum() >= 700
+    # reads of different lengths, thresholds in percent (0 for the short
+    # ones: the exact search; the others through the pigeonhole path)
+    rng = np.random.default_rng(5)
+    cut = [hq.symbols[int(s):int(s) + int(rng.integers(30, 101))]
+           for s in hq.start[:600]]
+    rq = H.Queries.from_list(cut)
+    got = V.findapproxcompletematches(
+        ix, V.Queries.from_host(rq.symbols, rq.start, rq.length), True, 2,
+        True).fetch()
+    assert np.array_equal(got, H.oracle_approx(host, rq, True, 2, True))
+    # the lcp-interval tree path (approx_tree.inc) with suffix array
+    # intervals beyond 2^32: patterns that are not cut (28 symbols, one
+    # error: esaapm / esahamming on the whole pattern).  The oracle walks the
+    # whole suffix array per pattern as the reference does -- hours at this
+    # size -- so the lists are checked through what they must hold: every
+    # occurrence with at most one mismatch contains one half of the pattern
+    # exactly (found by the oracle's exact search), every reported match is
+    # verified in the text, and every Hamming occurrence is an edit distance
+    # start.  (The order of these lists is pinned by the golden case c6, on
+    # 32- and 64-bit tables.)
+    m, k = 28, 1
+    top = hq.start[-120:]
+    pats = [hq.symbols[int(s):int(s) + m] for s in top]
+    tq = H.Queries.from_list(pats)
+    gt = V.Queries.from_host(tq.symbols, tq.start, tq.length)
+    halves = H.Queries.from_list([p[o:o + m // 2] for p in pats
+                                  for o in (0, m // 2)])
+    seeds = H.oracle_complete(host, halves)
+    tis = host.tis
+    expect = set()
+    for row in seeds:
+        q, o = int(row["queryseq"]) // 2, (int(row["queryseq"]) % 2) * (m // 2)
+        s0 = int(row["dbstart"]) - o
+        if s0 < 0 or s0 + m > N:
+            continue
+        w = tis[s0:s0 + m]
+        mm = int((w != pats[q]).sum())
+        if mm <= k and not (w == H.SEPARATOR).any():
+            expect.add((m, s0, q, mm))
+    got = V.findapproxcompletematches(ix, gt, False, k).fetch()
+    assert set(tuple(int(x) for x in r) for r in got) == expect
+    assert len(got) == len(expect) >= len(pats) // 2
+    assert (np.diff(got["queryseq"].astype(np.int64)) >= 0).all()
+    if N + 1 >= 1 << 32:
+        assert (got["dbstart"] >= 1 << 32).sum() >= len(pats) // 2
+    edit = V.findapproxcompletematches(ix, gt, True, k).fetch()
+    starts = set((int(r["dbstart"]), int(r["queryseq"])) for r in edit)
+    assert all((s0, q) in starts for (_, s0, q, _) in expect)
+    for r in edit[:: max(1, len(edit) // 400)]:
+        ln, s0, q, dist = (int(r[f]) for f in
+                           ("length", "dbstart", "queryseq", "querystart"))
+        pat, best = pats[q], None
+        prev = list(range(m + 1))        # column of the empty text prefix
+        for L in range(1, min(m + k, N - s0) + 1):
+            c = tis[s0 + L - 1]
+            if c == H.SEPARATOR:
+                break
+            cur = [L] + [0] * m
+            for i in range(1, m + 1):
+                cur[i] = min(prev[i - 1] + (0 if pat[i - 1] == c and c < 254
+                                            else 1), prev[i] + 1,
+                             cur[i - 1] + 1)
+            if best is None or cur[m] <= best[1]:
+                best = (L, cur[m])     # the longest among the best
+            prev = cur
+        assert best == (ln, dist) and dist <= k, (r, best)
+
+
 def test_self_index_scan_on_the_wide_index(V, world):
     """vmatch -mum on an index that holds two "genomes" (the first and the
     second half of the text, vsa_index_set_queryseparator): the streaming

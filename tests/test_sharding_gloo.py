@@ -89,6 +89,20 @@ def _worker(rank, world, port, outdir):
         dist, torch, torch.from_numpy(rows.astype(np.int64).reshape(-1)),
         send, top, "cpu", packed_filter_fn, words=2)
     assert (rn, rs, rc_) == (nmum, sumlen, ncand)
+    # ... and with the rows for the rank itself behind all others
+    # (vsa_result_partition_own): they do not enter the exchange, the filter
+    # gets them and the received rows as two lists
+    gdest = (grouped["dbstart"] * np.uint64(world)) // np.uint64(idx.n + 1)
+    ownlast = np.concatenate([rows[gdest != rank], rows[gdest == rank]])
+
+    def two_lists_filter_fn(own, received, carry):
+        assert own.numel() // 2 == int(send[rank])
+        return packed_filter_fn(torch.cat([received, own]), carry)
+
+    on, os_, oc = S.partitioned_mum_filter_presorted(
+        dist, torch, torch.from_numpy(ownlast.astype(np.int64).reshape(-1)),
+        send, top, "cpu", two_lists_filter_fn, words=2, own_last=True)
+    assert (on, os_, oc) == (nmum, sumlen, ncand)
     pparts, _ = S.all_gather_matches(
         dist, torch, S.matches_to_tensor(torch, result["mymums"]), "cpu")
     totals = S.all_reduce_counters(dist, torch,

@@ -151,6 +151,7 @@ def _load():
         "vsa_findquerymatches": (I, [V, V, I, I, U64, PP]),
         "vsa_findmumcandidates": (I, [V, V, U64, I, PP]),
         "vsa_result_partition": (I, [V, U32, U64, V, V, V]),
+        "vsa_result_partition_own": (I, [V, U32, I, U64, V, V, V]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
         "vsa_findmaximaluniquematches_range": (I, [V, U64, U64, U64, PP]),
         "vsa_findmaximalrepeats": (I, [V, U64, PP]),
@@ -162,6 +163,8 @@ def _load():
         "vsa_result_packbits": (C.c_uint32, [V]),
         "vsa_mumuniqueinquery_range_packed": (
             I, [V, U64, C.c_uint32, U64, I, U64, PP]),
+        "vsa_mumuniqueinquery_range_packed2": (
+            I, [V, U64, V, U64, C.c_uint32, U64, I, U64, PP]),
         "vsa_findtandems_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findcompletematches_cb": (I, [V, V, PROCESSMATCH, V]),
         "vsa_findquerymatches_cb": (I, [V, V, I, I, U64, PROCESSMATCH, V]),
@@ -368,14 +371,15 @@ class Result:
     def copy_device(self, device_ptr, capacity):
         _check(lib.vsa_result_copy_device(self._h, device_ptr, capacity))
 
-    def partition(self, nparts, totallength, device_ptr):
+    def partition(self, nparts, totallength, device_ptr, own=-1):
         """records grouped by the index range of their dbstart, written to
-        device_ptr; -> (number of records, largest right end) per part"""
+        device_ptr; -> (number of records, largest right end) per part.
+        own >= 0: that part lies behind all others"""
         counts = np.zeros(nparts, np.uint64)
         maxright = np.zeros(nparts, np.uint64)
-        _check(lib.vsa_result_partition(self._h, int(nparts),
-                                        int(totallength), device_ptr,
-                                        _ptr(counts), _ptr(maxright)))
+        _check(lib.vsa_result_partition_own(self._h, int(nparts), int(own),
+                                            int(totallength), device_ptr,
+                                            _ptr(counts), _ptr(maxright)))
         return counts, maxright
 
     @property
@@ -532,6 +536,18 @@ def mumuniqueinquery_range_packed(device_rows, nrows, lengthbits, totallength,
     _check(lib.vsa_mumuniqueinquery_range_packed(
         device_rows, int(nrows), int(lengthbits), int(totallength), device,
         int(carry_dbright), C.byref(h)))
+    return Result(h)
+
+
+def mumuniqueinquery_range_packed2(device_rows, nrows, more_rows, nmore,
+                                   lengthbits, totallength, carry_dbright,
+                                   device=0):
+    """the filter on one dbstart range of packed candidate rows that lie in
+    two places (own rows, received rows)"""
+    h = C.c_void_p()
+    _check(lib.vsa_mumuniqueinquery_range_packed2(
+        device_rows, int(nrows), more_rows, int(nmore), int(lengthbits),
+        int(totallength), device, int(carry_dbright), C.byref(h)))
     return Result(h)
 
 

@@ -2503,6 +2503,14 @@ struct PartInput
   const vsa_match *m;
   const uint64_t *key, *val;
   uint32_t packbits;
+  // the part written behind all others (a rank's own: it does not travel),
+  // its place among the parts and the number of parts; own = nparts: none
+  uint32_t own, nparts;
+  // part -> its place in the output
+  __device__ __forceinline__ uint32_t place(uint32_t p) const
+  {
+    return p < own ? p : (p == own ? nparts - 1 : p - 1);
+  }
 };
 
 __device__ __forceinline__ void part_read(const PartInput &in, uint64_t t,
@@ -2543,7 +2551,8 @@ k_partition_count(const PartInput in, uint64_t n,
   {
     uint64_t dbstart, length;
     part_read(in, t, dbstart, length);
-    const uint32_t p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
+    const uint32_t p =
+        in.place((uint32_t) ((dbstart * nparts) / (totallength + 1)));
     atomicAdd(&hist[p], 1u);
     // right end of the match in the index (cleanMUMcand.c: dbright)
     atomicMax(&top[p], (unsigned long long) (dbstart + length - 1));
@@ -2615,8 +2624,8 @@ k_partition_place(const PartInput in, uint64_t n,
   {
     // rows of two words: key, value
     const uint64_t k = in.key[t], v = in.val[t];
-    const uint32_t p =
-        (uint32_t) (((k >> in.packbits) * nparts) / (totallength + 1));
+    const uint32_t p = in.place(
+        (uint32_t) (((k >> in.packbits) * nparts) / (totallength + 1)));
     const uint64_t slot = offsets[(uint64_t) p * nblocks + vsa_bid()] +
                           atomicAdd(&taken[p], 1u);
     uint4 row;
@@ -2630,7 +2639,8 @@ k_partition_place(const PartInput in, uint64_t n,
     const uint4 *src = reinterpret_cast<const uint4 *>(in.m + t);
     const uint4 lo = src[0], hi = src[1];
     const uint64_t dbstart = ((uint64_t) lo.w << 32) | lo.z;
-    const uint32_t p = (uint32_t) ((dbstart * nparts) / (totallength + 1));
+    const uint32_t p =
+        in.place((uint32_t) ((dbstart * nparts) / (totallength + 1)));
     const uint64_t slot = offsets[(uint64_t) p * nblocks + vsa_bid()] +
                           atomicAdd(&taken[p], 1u);
     uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<vsa_match *>(out) +
@@ -2640,16 +2650,288 @@ k_partition_place(const PartInput in, uint64_t n,
   }
 }
 
-extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
-                                    uint64_t totallength,
-                                    void *device_matches, uint64_t *counts,
-                                    uint64_t *maxright)
+// ---- up to 8 parts (the ranks of one node): tiles of 2 048 records, eight
+// per lane, everything counted in registers.  The kernels above spend their
+// time in LDS atomics that all 256 lanes aim at the same few words (one part:
+// one word) and in a 64-bit division per record; here a record's part is a sum
+// of comparisons with the seven range boundaries, counts and largest right
+// ends are kept per lane and part and reduced once per tile across the
+// wavefront (DPP), and the tile leaves through LDS grouped by part, so that
+// the rows of a part are written as one contiguous run.
+#define VSA_PT_ITEMS 8
+#define VSA_PT_TILE (VSA_BLOCK * VSA_PT_ITEMS)
+#define VSA_PT_SMALL 8
+
+#define VSA_DPP64(old, v, ctrl, rowmask)                                      \
+  (((uint64_t) (uint32_t) __builtin_amdgcn_update_dpp(                        \
+        (int) ((old) >> 32), (int) ((v) >> 32), ctrl, rowmask, 0xF, false)    \
+    << 32) |                                                                  \
+   (uint32_t) __builtin_amdgcn_update_dpp((int) (old), (int) (v), ctrl,       \
+                                          rowmask, 0xF, false))
+
+// lane 63 receives the maximum of all 64 lanes (an inclusive scan with max;
+// lanes without a source keep their own value)
+__device__ __forceinline__ uint64_t vsa_wave_inclusive_max64(uint64_t x)
+{
+  uint64_t y;
+  y = VSA_DPP64(x, x, 0x111, 0xF); x = y > x ? y : x; // row_shr:1
+  y = VSA_DPP64(x, x, 0x112, 0xF); x = y > x ? y : x; // row_shr:2
+  y = VSA_DPP64(x, x, 0x114, 0xF); x = y > x ? y : x; // row_shr:4
+  y = VSA_DPP64(x, x, 0x118, 0xF); x = y > x ? y : x; // row_shr:8
+  y = VSA_DPP64(x, x, 0x142, 0xA); x = y > x ? y : x; // row_bcast:15
+  y = VSA_DPP64(x, x, 0x143, 0xC); x = y > x ? y : x; // row_bcast:31
+  return x;
+}
+
+// first position of part j: ceil(j (T + 1) / nparts); nothing lies in the
+// parts from nparts on
+__device__ __forceinline__ void part_bounds(uint64_t *bound, uint32_t nparts,
+                                            uint64_t totallength)
+{
+  if (threadIdx.x <= VSA_PT_SMALL)
+  {
+    const uint64_t j = threadIdx.x;
+    bound[j] = (j < nparts) ? (j * (totallength + 1) + nparts - 1) / nparts
+                            : ~0ull;
+  }
+}
+
+struct PartBounds
+{
+  uint64_t b[VSA_PT_SMALL - 1];
+  __device__ __forceinline__ void load(const uint64_t *bound)
+  {
+#pragma unroll
+    for (int j = 0; j < VSA_PT_SMALL - 1; j++)
+    {
+      b[j] = bound[j + 1];
+    }
+  }
+  __device__ __forceinline__ uint32_t part(uint64_t dbstart) const
+  {
+    uint32_t p = 0;
+#pragma unroll
+    for (int j = 0; j < VSA_PT_SMALL - 1; j++)
+    {
+      p += dbstart >= b[j] ? 1u : 0u;
+    }
+    return p;
+  }
+};
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_partition_count_small(const PartInput in, uint64_t n, uint32_t nparts,
+                        uint64_t totallength, uint64_t ntiles,
+                        uint32_t *__restrict__ blockhist,
+                        unsigned long long *__restrict__ blocktop)
+{
+  __shared__ uint64_t bound[VSA_PT_SMALL + 1];
+  __shared__ uint32_t wcount[VSA_BLOCK / 64][VSA_PT_SMALL];
+  __shared__ uint64_t wtop[VSA_BLOCK / 64][VSA_PT_SMALL];
+  const uint64_t tile = vsa_bid();
+  if (tile >= ntiles) // surplus block of a folded grid
+  {
+    return;
+  }
+  part_bounds(bound, nparts, totallength);
+  __syncthreads();
+  PartBounds pb;
+  pb.load(bound);
+  uint32_t cnt[VSA_PT_SMALL];
+  uint64_t top[VSA_PT_SMALL];
+#pragma unroll
+  for (int j = 0; j < VSA_PT_SMALL; j++)
+  {
+    cnt[j] = 0;
+    top[j] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < VSA_PT_ITEMS; i++)
+  {
+    const uint64_t t = tile * VSA_PT_TILE + (uint64_t) i * VSA_BLOCK +
+                       threadIdx.x;
+    if (t < n)
+    {
+      uint64_t dbstart, length;
+      part_read(in, t, dbstart, length);
+      const uint32_t p = in.place(pb.part(dbstart));
+      // right end of the match in the index (cleanMUMcand.c: dbright)
+      const uint64_t right = dbstart + length - 1;
+#pragma unroll
+      for (int j = 0; j < VSA_PT_SMALL; j++)
+      {
+        const bool hit = p == (uint32_t) j;
+        cnt[j] += hit ? 1u : 0u;
+        top[j] = (hit && right > top[j]) ? right : top[j];
+      }
+    }
+  }
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < VSA_PT_SMALL; j++)
+  {
+    const uint32_t c = vsa_wave_inclusive_sum(cnt[j]);
+    const uint64_t m = vsa_wave_inclusive_max64(top[j]);
+    if (lane == 63)
+    {
+      wcount[w][j] = c;
+      wtop[w][j] = m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nparts)
+  {
+    uint32_t c = 0;
+    uint64_t m = 0;
+    for (uint32_t k = 0; k < VSA_BLOCK / 64; k++)
+    {
+      c += wcount[k][threadIdx.x];
+      m = wtop[k][threadIdx.x] > m ? wtop[k][threadIdx.x] : m;
+    }
+    blockhist[(uint64_t) threadIdx.x * ntiles + tile] = c;
+    blocktop[(uint64_t) threadIdx.x * ntiles + tile] = m;
+  }
+}
+
+// pairs (key, value) only: a tile of records would not fit the 64 KB of LDS
+// a workgroup may declare
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_partition_place_small(const PartInput in, uint64_t n, uint32_t nparts,
+                        uint64_t totallength, uint64_t ntiles,
+                        const uint64_t *__restrict__ offsets,
+                        uint4 *__restrict__ out)
+{
+  __shared__ uint64_t bound[VSA_PT_SMALL + 1];
+  __shared__ uint32_t wcount[VSA_BLOCK / 64][VSA_PT_SMALL];
+  __shared__ uint32_t localbase[VSA_PT_SMALL + 1];
+  __shared__ uint64_t globalbase[VSA_PT_SMALL];
+  __shared__ uint4 stage[VSA_PT_TILE];
+  const uint64_t tile = vsa_bid();
+  if (tile >= ntiles) // surplus block of a folded grid
+  {
+    return;
+  }
+  part_bounds(bound, nparts, totallength);
+  if (threadIdx.x < VSA_PT_SMALL)
+  {
+    globalbase[threadIdx.x] =
+        threadIdx.x < nparts
+            ? offsets[(uint64_t) threadIdx.x * ntiles + tile]
+            : 0;
+  }
+  __syncthreads();
+  PartBounds pb;
+  pb.load(bound);
+  uint4 row[VSA_PT_ITEMS];
+  uint32_t parts = 0; // 4 bits per item: its part, 15 = no item
+  uint32_t cnt[VSA_PT_SMALL];
+#pragma unroll
+  for (int j = 0; j < VSA_PT_SMALL; j++)
+  {
+    cnt[j] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < VSA_PT_ITEMS; i++)
+  {
+    const uint64_t t = tile * VSA_PT_TILE + (uint64_t) i * VSA_BLOCK +
+                       threadIdx.x;
+    uint32_t p = 15;
+    row[i] = make_uint4(0, 0, 0, 0);
+    if (t < n)
+    {
+      const uint64_t k = in.key[t], v = in.val[t];
+      row[i] = make_uint4((uint32_t) k, (uint32_t) (k >> 32), (uint32_t) v,
+                          (uint32_t) (v >> 32));
+      p = in.place(pb.part(k >> in.packbits));
+    }
+    parts |= p << (4 * i);
+#pragma unroll
+    for (int j = 0; j < VSA_PT_SMALL; j++)
+    {
+      cnt[j] += p == (uint32_t) j ? 1u : 0u;
+    }
+  }
+  // where this lane's rows of part j start inside the tile's run of part j
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t before[VSA_PT_SMALL];
+#pragma unroll
+  for (int j = 0; j < VSA_PT_SMALL; j++)
+  {
+    const uint32_t incl = vsa_wave_inclusive_sum(cnt[j]);
+    before[j] = incl - cnt[j];
+    if (lane == 63)
+    {
+      wcount[w][j] = incl;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t run = 0;
+    for (int j = 0; j < VSA_PT_SMALL; j++)
+    {
+      localbase[j] = run;
+      for (uint32_t k = 0; k < VSA_BLOCK / 64; k++)
+      {
+        run += wcount[k][j];
+      }
+    }
+    localbase[VSA_PT_SMALL] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < VSA_PT_SMALL; j++)
+  {
+    uint32_t lower = localbase[j];
+    for (uint32_t k = 0; k < w; k++)
+    {
+      lower += wcount[k][j];
+    }
+    before[j] += lower;
+  }
+#pragma unroll
+  for (int i = 0; i < VSA_PT_ITEMS; i++)
+  {
+    const uint32_t p = (parts >> (4 * i)) & 15;
+    uint32_t at = 0;
+#pragma unroll
+    for (int j = 0; j < VSA_PT_SMALL; j++)
+    {
+      const bool hit = p == (uint32_t) j;
+      at = hit ? before[j] : at;
+      before[j] += hit ? 1u : 0u;
+    }
+    if (p != 15)
+    {
+      stage[at] = row[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t total = localbase[VSA_PT_SMALL];
+  for (uint32_t r = threadIdx.x; r < total; r += VSA_BLOCK)
+  {
+    uint32_t p = 0;
+#pragma unroll
+    for (int j = 1; j < VSA_PT_SMALL; j++)
+    {
+      p += r >= localbase[j] ? 1u : 0u;
+    }
+    out[globalbase[p] + (r - localbase[p])] = stage[r];
+  }
+}
+
+extern "C" int vsa_result_partition_own(const vsa_result *result,
+                                        uint32_t nparts, int ownpart,
+                                        uint64_t totallength,
+                                        void *device_matches, uint64_t *counts,
+                                        uint64_t *maxright)
 {
   if (result == nullptr || counts == nullptr || nparts == 0 ||
-      nparts > VSA_PART_MAX ||
+      nparts > VSA_PART_MAX || ownpart >= (int) nparts ||
       (result->count > 0 && device_matches == nullptr))
   {
-    VSA_ERROR("vsa_result_partition: bad argument (1..256 parts)");
+    VSA_ERROR("vsa_result_partition: bad argument (1..256 parts, own part "
+              "among them or < 0)");
     return -1;
   }
   for (uint32_t p = 0; p < nparts; p++)
@@ -2671,7 +2953,18 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   }
   hipStream_t stream = nullptr;
   vsa_dev_set_stream(stream);
-  const uint64_t nblocks = blocksfor(n), cells = (uint64_t) nparts * nblocks;
+  // tiles of eight records per lane for pairs that go to up to 8 parts
+  // (VSA_PARTITION_SMALL=0: the general kernels, for comparison)
+  static const bool smallok = []() {
+    const char *e = getenv("VSA_PARTITION_SMALL");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  const bool small = smallok && nparts <= VSA_PT_SMALL &&
+                     result->packbits != 0;
+  const uint64_t nblocks =
+                     small ? (n + VSA_PT_TILE - 1) / VSA_PT_TILE
+                           : blocksfor(n),
+                 cells = (uint64_t) nparts * nblocks;
   DevBuf hist, top, offsets, summary, temp;
   uint64_t host[2 * VSA_PART_MAX + 1];
   size_t tb = 0;
@@ -2686,10 +2979,20 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
   in.key = reinterpret_cast<const uint64_t *>(result->matches);
   in.val = result->packvals;
   in.packbits = result->packbits;
+  in.nparts = nparts;
+  in.own = ownpart < 0 ? nparts : (uint32_t) ownpart;
   VSA_HIP(hipMemsetAsync(hist.as<uint32_t>() + cells, 0, 4, stream));
-  k_partition_count<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
-      in, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
-      top.as<unsigned long long>());
+  if (small)
+  {
+    k_partition_count_small<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
+        in, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
+        top.as<unsigned long long>());
+  } else
+  {
+    k_partition_count<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
+        in, n, nparts, totallength, nblocks, hist.as<uint32_t>(),
+        top.as<unsigned long long>());
+  }
   VSA_HIP(hipGetLastError());
   auto widen = rocprim::make_transform_iterator(hist.as<uint32_t>(),
                                                 U32ToU64());
@@ -2708,23 +3011,317 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
       summary.as<uint64_t>(),
       summary.as<unsigned long long>() + VSA_PART_MAX + 1);
   VSA_HIP(hipGetLastError());
-  k_partition_place<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
-      in, n, nparts, totallength, nblocks, offsets.as<uint64_t>(),
-      device_matches);
+  if (small)
+  {
+    k_partition_place_small<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
+        in, n, nparts, totallength, nblocks, offsets.as<uint64_t>(),
+        reinterpret_cast<uint4 *>(device_matches));
+  } else
+  {
+    k_partition_place<<<vsa_grid(nblocks), VSA_BLOCK, 0, stream>>>(
+        in, n, nparts, totallength, nblocks, offsets.as<uint64_t>(),
+        device_matches);
+  }
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipMemcpyAsync(host, summary.p, (2 * VSA_PART_MAX + 1) * 8,
                          hipMemcpyDeviceToHost, stream));
   VSA_HIP(hipStreamSynchronize(stream));
   for (uint32_t p = 0; p < nparts; p++)
   {
-    counts[p] = host[p + 1] - host[p];
+    // (the device counted by place in the output)
+    const uint32_t at = p < in.own ? p : (p == in.own ? nparts - 1 : p - 1);
+    counts[p] = host[at + 1] - host[at];
     if (maxright != nullptr)
     {
-      maxright[p] = host[VSA_PART_MAX + 1 + p];
+      maxright[p] = host[VSA_PART_MAX + 1 + at];
     }
   }
   return 0;
 }
+
+extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
+                                    uint64_t totallength,
+                                    void *device_matches, uint64_t *counts,
+                                    uint64_t *maxright)
+{
+  return vsa_result_partition_own(result, nparts, -1, totallength,
+                                  device_matches, counts, maxright);
+}
+
+// ---- batches whose thresholds (-e Kp / -h Kp) are 0 for the short reads and
+// > 0 for the long ones: the reference sends the former through the exact
+// search and the latter through splitesaapm, read by read
+// (Vmengine/approxcompl.c:167-191).  Here the batch is cut into the two kinds,
+// each kind runs as a batch of its own over the same symbols, and the two
+// lists are merged back into query order.
+
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_subquery_gather(const uint64_t *__restrict__ start,
+                  const uint64_t *__restrict__ length,
+                  const uint64_t *__restrict__ which, uint64_t n,
+                  uint64_t *__restrict__ substart,
+                  uint64_t *__restrict__ sublength)
+{
+  const uint64_t i = vsa_bid() * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    const uint64_t q = which[i];
+    substart[i] = start[q];
+    sublength[i] = length[q];
+  }
+}
+
+// rows [0, nfirst) come from the sub-batch `whicha`, the others from
+// `whichb`; their queryseq becomes the number in the whole batch
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_subquery_renumber(vsa_match *__restrict__ rows, uint64_t nfirst,
+                    uint64_t n, const uint64_t *__restrict__ whicha,
+                    const uint64_t *__restrict__ whichb, uint64_t seqoffset,
+                    uint32_t *__restrict__ keys, uint32_t *__restrict__ index)
+{
+  const uint64_t i = vsa_bid() * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    const uint64_t sub = rows[i].queryseq;
+    const uint64_t q = (i < nfirst) ? whicha[sub] : whichb[sub];
+    rows[i].queryseq = q + seqoffset;
+    keys[i] = (uint32_t) q;
+    index[i] = (uint32_t) i;
+  }
+}
+
+namespace
+{
+
+struct SubQueries
+{
+  vsa_queries q;
+  DevBuf start, length, which;
+};
+
+// the queries `which` (ascending numbers) of a batch as a batch that shares
+// the symbols
+int make_subqueries(const vsa_index *index, const vsa_queries *queries,
+                    const std::vector<uint64_t> &which, SubQueries &sub)
+{
+  const uint64_t n = which.size();
+
+  sub.q.device = queries->device;
+  sub.q.nq = n;
+  sub.q.nsymbols = queries->nsymbols;
+  sub.q.symbols = queries->symbols;
+  sub.q.seqoffset = 0;
+  sub.q.dense = false;
+  sub.q.hlength.resize(n);
+  sub.q.minlength = n ? ~0ull : 0;
+  sub.q.maxlength = 0;
+  for (uint64_t i = 0; i < n; i++)
+  {
+    const uint64_t m = queries->hlength[which[i]];
+    sub.q.hlength[i] = m;
+    sub.q.minlength = std::min(sub.q.minlength, m);
+    sub.q.maxlength = std::max(sub.q.maxlength, m);
+  }
+  sub.q.uniform = n != 0 && sub.q.minlength == sub.q.maxlength;
+  vsa_dev_set_stream(index->stream);
+  if (sub.start.alloc(n * 8) || sub.length.alloc(n * 8) ||
+      sub.which.alloc(n * 8))
+  {
+    return -100;
+  }
+  sub.q.start = sub.start.as<uint64_t>();
+  sub.q.length = sub.length.as<uint64_t>();
+  if (n > 0)
+  {
+    VSA_HIP(hipMemcpyAsync(sub.which.p, which.data(), n * 8,
+                           hipMemcpyHostToDevice, index->stream));
+    k_subquery_gather<<<gridfor(n), VSA_BLOCK, 0, index->stream>>>(
+        queries->start, queries->length, sub.which.as<uint64_t>(), n,
+        sub.q.start, sub.q.length);
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipStreamSynchronize(index->stream));
+  }
+  return 0;
+}
+
+int approx_batch(const vsa_index *index, const vsa_queries *queries,
+                 int doedist, uint64_t distvalue, int percent,
+                 vsa_result **result);
+
+int approx_mixed(const vsa_index *index, const vsa_queries *queries,
+                 int doedist, uint64_t distvalue, vsa_result **result)
+{
+  const uint64_t nq = queries->nq;
+  std::vector<uint64_t> exact, approx;
+  uint64_t qlimit = nq, failk = 0, failm = 0;
+  bool failshort = false;
+
+  if (nq >= 0xFFFFFFFFull)
+  {
+    VSA_ERROR("a batch of %lu reads that mixes thresholds 0 and > 0 is not "
+              "covered by the GPU engine", (unsigned long) nq);
+    return VSA_NOT_COVERED;
+  }
+  for (uint64_t q = 0; q < nq; q++)
+  {
+    const uint64_t m = queries->hlength[q], k = (m * distvalue) / 100;
+    if (k == 0)
+    {
+      if (m < index->pl)
+      {
+        // exactcompl.c:179-185
+        qlimit = q;
+        failshort = true;
+        failm = m;
+        break;
+      }
+      exact.push_back(q);
+    } else
+    {
+      if (k >= m)
+      {
+        // splitesaapm.c:496-501
+        qlimit = q;
+        failk = k;
+        failm = m;
+        break;
+      }
+      approx.push_back(q);
+    }
+  }
+  SubQueries sa, sb;
+  vsa_result *ra = nullptr, *rb = nullptr;
+  int rc = 0;
+  if (!exact.empty())
+  {
+    rc = make_subqueries(index, queries, exact, sa);
+    if (rc == 0)
+    {
+      rc = vsa_findcompletematches(index, &sa.q, &ra);
+    }
+  }
+  if (rc == 0 && !approx.empty())
+  {
+    rc = make_subqueries(index, queries, approx, sb);
+    if (rc == 0)
+    {
+      rc = approx_batch(index, &sb.q, doedist, distvalue, 1, &rb);
+    }
+  }
+  if (rc != 0)
+  {
+    vsa_result_free(ra);
+    vsa_result_free(rb);
+    return rc;
+  }
+  if (vsa_set_device(index->device) != 0)
+  {
+    vsa_result_free(ra);
+    vsa_result_free(rb);
+    return -100;
+  }
+  hipStream_t stream = index->stream;
+  vsa_dev_set_stream(stream);
+  vsa_result *res = newresult(index->device);
+  const uint64_t na = ra ? ra->count : 0, nb = rb ? rb->count : 0,
+                 n = na + nb;
+  // (a macro that returns would leak the three lists)
+  auto merge = [&]() -> int {
+    DevBuf all, merged, keys, keys2, order, order2, temp;
+    size_t tb = 0;
+    if (n == 0)
+    {
+      return 0;
+    }
+    if (n >= 0xFFFFFFFFull)
+    {
+      VSA_ERROR("%lu matches of a batch that mixes thresholds 0 and > 0 are "
+                "not covered by the GPU engine", (unsigned long) n);
+      return VSA_NOT_COVERED;
+    }
+    if (all.alloc(n * sizeof(vsa_match)) ||
+        merged.alloc(n * sizeof(vsa_match)) || keys.alloc(n * 4) ||
+        keys2.alloc(n * 4) || order.alloc(n * 4) || order2.alloc(n * 4))
+    {
+      return -100;
+    }
+    if (na > 0)
+    {
+      VSA_HIP(hipMemcpyAsync(all.p, ra->matches, na * sizeof(vsa_match),
+                             hipMemcpyDeviceToDevice, stream));
+    }
+    if (nb > 0)
+    {
+      VSA_HIP(hipMemcpyAsync(all.as<vsa_match>() + na, rb->matches,
+                             nb * sizeof(vsa_match), hipMemcpyDeviceToDevice,
+                             stream));
+    }
+    k_subquery_renumber<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+        all.as<vsa_match>(), na, n, sa.which.as<uint64_t>(),
+        sb.which.as<uint64_t>(), queries->seqoffset, keys.as<uint32_t>(),
+        order.as<uint32_t>());
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(rocprim::radix_sort_pairs(
+        nullptr, tb, keys.as<uint32_t>(), keys2.as<uint32_t>(),
+        order.as<uint32_t>(), order2.as<uint32_t>(), (size_t) n, 0u,
+        bitsfor(nq), stream));
+    if (temp.alloc(tb))
+    {
+      return -100;
+    }
+    VSA_HIP(rocprim::radix_sort_pairs(
+        temp.p, tb, keys.as<uint32_t>(), keys2.as<uint32_t>(),
+        order.as<uint32_t>(), order2.as<uint32_t>(), (size_t) n, 0u,
+        bitsfor(nq), stream));
+    k_gather_matches<<<gridfor(n), VSA_BLOCK, 0, stream>>>(
+        all.as<vsa_match>(), order2.as<uint32_t>(), n,
+        merged.as<vsa_match>());
+    VSA_HIP(hipGetLastError());
+    VSA_HIP(hipStreamSynchronize(stream));
+    res->matches = (vsa_match *) merged.release();
+    return 0;
+  };
+  rc = merge();
+  res->count = res->stats.count = n;
+  for (const vsa_result *r : {(const vsa_result *) ra,
+                              (const vsa_result *) rb})
+  {
+    if (r != nullptr)
+    {
+      res->stats.sumlength += r->stats.sumlength;
+      res->stats.searches += r->stats.searches;
+      res->stats.kernel_searches += r->stats.kernel_searches;
+      res->stats.search_kernel_ms += r->stats.search_kernel_ms;
+      res->stats.total_device_ms += r->stats.total_device_ms;
+      res->stats.first_kernel_ms += r->stats.first_kernel_ms;
+    }
+  }
+  vsa_result_free(ra);
+  vsa_result_free(rb);
+  if (rc != 0)
+  {
+    vsa_result_free(res);
+    return rc;
+  }
+  *result = res;
+  if (qlimit < nq)
+  {
+    // the reads before the failing one have been answered
+    if (failshort)
+    {
+      VSA_ERROR("patternlength=%lu must be >= %lu=prefixlen",
+                (unsigned long) failm, (unsigned long) index->pl);
+    } else
+    {
+      VSA_ERROR("threshold=%lu>=%lu=patternlen not allowed",
+                (unsigned long) failk, (unsigned long) failm);
+    }
+    return -2;
+  }
+  return 0;
+}
+
+} // namespace
 
 extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
                                              const vsa_queries *queries,
@@ -2737,6 +3334,29 @@ extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
     VSA_ERROR("vsa_findapproxcompletematches: NULL argument");
     return -1;
   }
+  *result = nullptr;
+  if (queries->device != index->device)
+  {
+    VSA_ERROR("queries live on device %d, index on device %d",
+              queries->device, index->device);
+    return -1;
+  }
+  if (percent != 0 && index->bck != nullptr && index->numofchars == 4 &&
+      (queries->minlength * distvalue) / 100 == 0 &&
+      (queries->maxlength * distvalue) / 100 != 0)
+  {
+    return approx_mixed(index, queries, doedist, distvalue, result);
+  }
+  return approx_batch(index, queries, doedist, distvalue, percent, result);
+}
+
+namespace
+{
+
+int approx_batch(const vsa_index *index, const vsa_queries *queries,
+                 int doedist, uint64_t distvalue, int percent,
+                 vsa_result **result)
+{
   *result = nullptr;
   if (index->bck == nullptr)
   {
@@ -2811,6 +3431,8 @@ extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
   }
   return 0;
 }
+
+} // namespace
 
 extern "C" int vsa_findquerymatches(const vsa_index *index,
                                     const vsa_queries *queries,
@@ -2931,13 +3553,15 @@ extern "C" int vsa_mumuniqueinquery_range(void *device_candidates,
 }
 
 // word 0 / word 1 of row i of (key, value) pairs
+// word 0 (key) or 1 (value) of row i of two lists of rows laid end to end
 struct RowWord
 {
-  const uint64_t *rows;
+  const uint64_t *rows, *more;
+  uint64_t nrows; // in `rows`
   uint32_t word;
   __device__ uint64_t operator()(size_t i) const
   {
-    return rows[2 * i + word];
+    return i < nrows ? rows[2 * i + word] : more[2 * (i - nrows) + word];
   }
 };
 
@@ -2970,17 +3594,19 @@ int vsa_unpack_result(const vsa_result *r, uint64_t count, vsa_match *device)
   return 0;
 }
 
-extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
-                                                 uint64_t nrows,
-                                                 uint32_t lengthbits,
-                                                 uint64_t totallength,
-                                                 int device,
-                                                 uint64_t carry_dbright,
-                                                 vsa_result **result)
+extern "C" int vsa_mumuniqueinquery_range_packed2(const void *device_rows,
+                                                  uint64_t nrows,
+                                                  const void *more_rows,
+                                                  uint64_t nmore,
+                                                  uint32_t lengthbits,
+                                                  uint64_t totallength,
+                                                  int device,
+                                                  uint64_t carry_dbright,
+                                                  vsa_result **result)
 {
   if (result == nullptr || (device_rows == nullptr && nrows > 0) ||
-      lengthbits == 0 || lengthbits > 16 ||
-      lengthbits + bitsfor(totallength) > 64)
+      (more_rows == nullptr && nmore > 0) || lengthbits == 0 ||
+      lengthbits > 16 || lengthbits + bitsfor(totallength) > 64)
   {
     VSA_ERROR("vsa_mumuniqueinquery_range_packed: bad argument");
     return -1;
@@ -2996,18 +3622,21 @@ extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
   Timer tall(stream);
   DevBuf mums;
   uint64_t nm = 0, sum = 0;
+  const uint64_t total = nrows + nmore;
   tall.start();
   int rc = 0;
-  if (nrows > 0)
+  if (total > 0)
   {
     // the sort reads the rows as they lie (the first pass of the radix sort
-    // takes iterators): no split into two arrays
-    const uint64_t *rows = reinterpret_cast<const uint64_t *>(device_rows);
+    // takes iterators): no split into two arrays, no copy of the two lists
+    // into one
+    const uint64_t *rows = reinterpret_cast<const uint64_t *>(device_rows),
+                   *more = reinterpret_cast<const uint64_t *>(more_rows);
     auto rowkeys = rocprim::make_transform_iterator(
-        rocprim::counting_iterator<size_t>(0), RowWord{rows, 0});
+        rocprim::counting_iterator<size_t>(0), RowWord{rows, more, nrows, 0});
     auto rowvals = rocprim::make_transform_iterator(
-        rocprim::counting_iterator<size_t>(0), RowWord{rows, 1});
-    rc = mumfilter_packed<uint64_t>(rowkeys, rowvals, nrows, lengthbits,
+        rocprim::counting_iterator<size_t>(0), RowWord{rows, more, nrows, 1});
+    rc = mumfilter_packed<uint64_t>(rowkeys, rowvals, total, lengthbits,
                                     bitsfor(totallength), stream, mums, &nm,
                                     &sum, carry_dbright);
   }
@@ -3021,11 +3650,24 @@ extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
   res->count = nm;
   res->matches = (vsa_match *) mums.release();
   res->stats.count = nm;
-  res->stats.candidates = nrows;
+  res->stats.candidates = total;
   res->stats.sumlength = sum;
   res->stats.total_device_ms = tall.ms();
   *result = res;
   return 0;
+}
+
+extern "C" int vsa_mumuniqueinquery_range_packed(const void *device_rows,
+                                                 uint64_t nrows,
+                                                 uint32_t lengthbits,
+                                                 uint64_t totallength,
+                                                 int device,
+                                                 uint64_t carry_dbright,
+                                                 vsa_result **result)
+{
+  return vsa_mumuniqueinquery_range_packed2(device_rows, nrows, nullptr, 0,
+                                            lengthbits, totallength, device,
+                                            carry_dbright, result);
 }
 
 extern "C" int vsa_findmaximalrepeats(const vsa_index *index,

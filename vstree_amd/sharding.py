@@ -11,6 +11,8 @@ Which step needs which collective:
                              the reference): all_gather of the candidate
                              lists, filter on rank 0
 """
+import os
+
 import numpy as np
 
 MATCH_WORDS = 4   # vsa_match = 4 x uint64
@@ -102,9 +104,31 @@ def _exchange_rows(dist, torch, rows, dest, device):
         return torch.cat(keep) if keep else rows[:0]
 
 
+_META = {}
+# VSA_META_STAGING=0: a fresh pageable tensor per batch (round 2's form)
+_STAGED = os.environ.get("VSA_META_STAGING", "1") != "0"
+
+
+def _meta_staging(torch, world, device):
+    """buffers of the metadata all-gather (2*world numbers per rank), with
+    numpy views of the page-locked ones"""
+    key = (world, str(device))
+    if key not in _META:
+        n = 2 * world
+        st = dict(
+            host_in=torch.empty(n, dtype=torch.int64).pin_memory(),
+            dev_in=torch.empty(n, dtype=torch.int64, device=device),
+            dev_out=torch.empty(n * world, dtype=torch.int64, device=device),
+            host_out=torch.empty(n * world, dtype=torch.int64).pin_memory())
+        st["np_in"] = st["host_in"].numpy()
+        st["np_out"] = st["host_out"].numpy()
+        _META[key] = st
+    return _META[key]
+
+
 def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
                                      device, filter_fn, words=MATCH_WORDS,
-                                     extra=(), reduce=True):
+                                     extra=(), reduce=True, own_last=False):
     """partitioned_mum_filter for candidates that vsa_result_partition has
     grouped by destination already (send[r] rows for rank r, maxright[r] =
     their largest right end): no sorting on this side and three collectives --
@@ -116,34 +140,57 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     follow the three results.  reduce=False: no all-reduce -- the counters
     returned are this rank's own, for a caller that sums them over many
     batches and reduces once at the end of the job (the only collective the
-    counters need)."""
+    counters need).
+    own_last=True: the rows for this rank itself lie BEHIND all others
+    (vsa_result_partition_own) and never enter the exchange: the all-to-all
+    runs over the rows in front of them with a split of 0 for the rank
+    itself, and filter_fn(own, received, carry) gets the two lists as they
+    lie (vsa_mumuniqueinquery_range_packed2 takes them as one)."""
     world, me = dist.get_world_size(), dist.get_rank()
     rows = rows.reshape(-1, words)
-    meta = torch.as_tensor(np.concatenate([np.asarray(send, np.int64),
-                                           np.asarray(maxright, np.int64)]),
-                           device=device)
     # which collectives the backend has is a property of the process group,
     # decided the same way on every rank before anything is sent (a fallback
     # inside `except` would let ranks that fail for another reason issue a
     # different collective than the others)
     rccl = dist.get_backend() == "nccl"
-    if rccl:
-        # one tensor in, one out: no list of outputs to allocate and stack
+    if rccl and _STAGED:
+        # one tensor in, one out, through page-locked staging buffers kept
+        # from batch to batch: no allocation, no pageable copy
+        st = _meta_staging(torch, world, device)
+        st["np_in"][:world] = send
+        st["np_in"][world:] = maxright
+        st["dev_in"].copy_(st["host_in"], non_blocking=True)
+        dist.all_gather_into_tensor(st["dev_out"], st["dev_in"])
+        st["host_out"].copy_(st["dev_out"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        table = st["np_out"].reshape(world, -1)   # [sender, 2*world]
+    elif rccl:
+        meta = torch.as_tensor(np.concatenate(
+            [np.asarray(send, np.int64), np.asarray(maxright, np.int64)]),
+            device=device)
         gathered = torch.empty(world * meta.numel(), dtype=meta.dtype,
                                device=device)
         dist.all_gather_into_tensor(gathered, meta)
-        table = gathered.reshape(world, -1).cpu().numpy()   # [sender, 2*world]
+        table = gathered.reshape(world, -1).cpu().numpy()
     else:
+        meta = torch.as_tensor(np.concatenate(
+            [np.asarray(send, np.int64), np.asarray(maxright, np.int64)]),
+            device=device)
         metas = [torch.zeros_like(meta) for _ in range(world)]
         dist.all_gather(metas, meta)
         table = torch.stack(metas).cpu().numpy()
-    sends, tops = table[:, :world], table[:, world:]
-    recv = [int(x) for x in sends[:, me]]
+    sends, tops = table[:, :world].copy(), table[:, world:].copy()
     # largest right end among ALL candidates of the ranges below mine
     carry = int(tops[:, :me].max()) if me > 0 else 0
+    nown = int(sends[me, me]) if own_last else 0
+    nrows = rows.shape[0]
+    if own_last:
+        # what a rank keeps does not travel
+        sends[np.arange(world), np.arange(world)] = 0
+    recv = [int(x) for x in sends[:, me]]
     mine = torch.empty((sum(recv), words), dtype=torch.int64, device=device)
     if rccl:
-        dist.all_to_all_single(mine, rows, recv,
+        dist.all_to_all_single(mine, rows[:nrows - nown], recv,
                                [int(x) for x in sends[me]])
     else:
         # backend without all-to-all (gloo in the CPU tests): gather all,
@@ -152,11 +199,17 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
                                       words)
         keep = []
         for r, p in enumerate(parts):
+            # (own_last: the diagonal of `sends` is 0 by now, which is what
+            # the layout -- own rows behind the others -- needs here)
             off = int(sends[r, :me].sum())
             keep.append(p.reshape(-1, words)[off:off + recv[r]])
         mine = torch.cat(keep) if keep else rows[:0]
-    nmum, sumlen = filter_fn(mine.reshape(-1), carry)
-    local = [nmum, sumlen, rows.shape[0]] + list(extra)
+    if own_last:
+        nmum, sumlen = filter_fn(rows[nrows - nown:].reshape(-1),
+                                 mine.reshape(-1), carry)
+    else:
+        nmum, sumlen = filter_fn(mine.reshape(-1), carry)
+    local = [nmum, sumlen, nrows] + list(extra)
     totals = (all_reduce_counters(dist, torch, local, device) if reduce
               else [int(v) for v in local])
     return tuple(totals) if extra else tuple(totals[:3])
