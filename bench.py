@@ -82,6 +82,10 @@ def parse():
     # one rank, but through the N > 1 code path with the real backend (RCCL):
     # process group, all-to-all / all-gather / all-reduce on device tensors
     ap.add_argument("--force-distributed", action="store_true")
+    ap.add_argument("--meta-on-host", action="store_true",
+                    help="N > 1 form: split sizes through the host "
+                         "(vsa_result_partition_own) instead of staying on "
+                         "the device")
     # N > 1: `torch` = one process per GPU (torch.distributed, RCCL), what the
     # driver launches; `c` = ONE process that drives all GPUs through
     # libvstree_amd_multi.so (vsa_multi_findmatches: a host thread per GPU,
@@ -571,6 +575,9 @@ def main():
             torch.cuda.synchronize()
 
     kernel_ms, first_ms, totals = [], [], None
+    rowbuf = [None]     # N > 1 form: the candidate rows, kept between batches
+    if distributed and not a.rehearse_on_one_gpu:
+        rowbuf[0] = torch.empty(2 * 1024, dtype=torch.int64, device="cuda")
 
     def one_step():
         """the hot path over the whole batch; returns (count, sumlength,
@@ -589,20 +596,40 @@ def main():
         # the order the kernel left them, grouped by the rank that filters
         # their range of the index
         # (as pairs of sort key and value, 16 bytes each: half the exchange)
-        r = V.findmumcandidates_packed(index, queries, L, lenbits)
-        s = r.stats()
-        kernel_ms.append(s.search_kernel_ms)
-        first_ms.append(s.first_kernel_ms)
-        mine = torch.empty(max(r.count, 1) * 2, dtype=torch.int64,
-                           device="cuda")[:r.count * 2]
+        # (with RCCL the split sizes and right ends stay on the device, where
+        # the all-gather reads them, and search and grouping are one call into
+        # the library: the row buffer is kept from batch to batch)
         # (the rows for this rank's own range behind the others: they stay
         # where they are, the exchange runs over the rows in front of them)
-        send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()),
-                                own=rank)
-        r.close()
+        ondev = not a.rehearse_on_one_gpu and not a.meta_on_host
+        send = top = None
+        if ondev:
+            meta = S.meta_device_buffer(torch, world, "cuda")
+            r, grouped = V.findmumcandidates_grouped(
+                index, queries, L, lenbits, world, rank,
+                C.c_void_p(rowbuf[0].data_ptr()), rowbuf[0].numel() // 2,
+                C.c_void_p(meta.data_ptr()))
+            if not grouped:
+                rowbuf[0] = torch.empty(int(r.count * 1.1 + 1024) * 2,
+                                        dtype=torch.int64, device="cuda")
+                r.partition_device(world, n, C.c_void_p(rowbuf[0].data_ptr()),
+                                   C.c_void_p(meta.data_ptr()), own=rank)
+            mine = rowbuf[0][:r.count * 2]
+            s = r.stats()
+        else:
+            r = V.findmumcandidates_packed(index, queries, L, lenbits)
+            s = r.stats()
+            mine = torch.empty(max(r.count, 1) * 2, dtype=torch.int64,
+                               device="cuda")[:r.count * 2]
+            send, top = r.partition(world, n, C.c_void_p(mine.data_ptr()),
+                                    own=rank)
+            r.close()
+        kernel_ms.append(s.search_kernel_ms)
+        first_ms.append(s.first_kernel_ms)
         cdev = "cuda"
         if a.rehearse_on_one_gpu:
             mine, cdev = mine.cpu(), "cpu"
+        # (ondev: the grouping is still queued; r goes after the exchange)
 
         # phase 2: the one exchange step (RCCL all-to-all) -- every rank runs
         # the uniqueness filter on its range with the carry of the lower ones
@@ -622,7 +649,9 @@ def main():
             S.partitioned_mum_filter_presorted(
                 dist, torch, mine, send, top, cdev, filter_fn, words=2,
                 extra=[s.searches, s.kernel_searches], reduce=False,
-                own_last=True)
+                own_last=True, meta_on_device=ondev)
+        if ondev:
+            r.close()
         totals = (nmum, sumlen, searches, ncand, ksearches)
 
     for _ in range(a.warmup):

@@ -310,6 +310,25 @@ int vsa_result_partition_own(const vsa_result *result, uint32_t nparts,
                              int ownpart, uint64_t totallength,
                              void *device_matches, uint64_t *counts,
                              uint64_t *maxright);
+/* ... with the 2 * nparts numbers -- counts[0 .. nparts-1], then
+   maxright[0 .. nparts-1] -- left in DEVICE memory (device_meta), where the
+   all-gather of the ranks reads them: the call does not wait for the GPU
+   (work is queued on the device's default stream). */
+int vsa_result_partition_device(const vsa_result *result, uint32_t nparts,
+                                int ownpart, uint64_t totallength,
+                                void *device_matches, uint64_t *device_meta);
+/* vsa_findmumcandidates_packed and vsa_result_partition_device (totallength
+   = that of the index) in one call, for a caller that keeps its row buffer
+   from batch to batch: 0 = the rows (vsa_result_count(*result) of them) lie
+   grouped in device_rows; 1 = there are more than `capacity` rows: nothing
+   was grouped, *result holds the candidates (make room, then
+   vsa_result_partition_device); < 0 as vsa_findmumcandidates_packed. */
+int vsa_findmumcandidates_grouped(const vsa_index *index,
+                                  const vsa_queries *queries,
+                                  uint64_t searchlength, uint32_t lengthbits,
+                                  uint32_t nparts, int ownpart,
+                                  void *device_rows, uint64_t capacity,
+                                  uint64_t *device_meta, vsa_result **result);
 
 /*
   findcompletematches for approximate matching on the index, vmatch

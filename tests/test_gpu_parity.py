@@ -879,6 +879,22 @@ def test_packed_candidates_and_filter_in_ranges(V):
             rows = np.zeros((r.count, 2), np.uint64)
             V.device_download(rows, dp)
             assert int(counts.sum()) == r.count
+            # the form that leaves the numbers on the device and does not wait
+            dm, dp2 = V.device_malloc(16 * world), V.device_malloc(
+                max(r.count * 16, 16))
+            r.partition_device(world, idx.n, dp2, dm, own=own)
+            meta, rows2 = np.zeros(2 * world, np.uint64), np.zeros_like(rows)
+            V.device_download(meta, dm)
+            V.device_download(rows2, dp2)
+            V.device_free(dm)
+            V.device_free(dp2)
+            assert np.array_equal(meta[:world], counts)
+            assert np.array_equal(meta[world:], top)
+            if world <= 8:      # (the tiled kernels place deterministically)
+                assert np.array_equal(rows2, rows)
+            assert np.array_equal(
+                rows2[np.lexsort((rows2[:, 1], rows2[:, 0]))],
+                rows[np.lexsort((rows[:, 1], rows[:, 0]))])
             if own >= 0:
                 # the layout: others ascending, the own part last; the two
                 # lists of the own-last form give the filter's answer for
@@ -934,6 +950,30 @@ def test_packed_candidates_and_filter_in_ranges(V):
                 off += cnt
             V.device_free(dp)
             assert np.array_equal(np.concatenate(pieces), want)
+    # search and grouping in one call, into a buffer the caller keeps
+    r = V.findmumcandidates_packed(gi, gq, 20, 7)
+    dp, dm = V.device_malloc(r.count * 16), V.device_malloc(16 * 4)
+    counts, top = r.partition(4, idx.n, dp, own=2)
+    rows = np.zeros((r.count, 2), np.uint64)
+    V.device_download(rows, dp)
+    dp2 = V.device_malloc(r.count * 16 + 64)
+    r2, grouped = V.findmumcandidates_grouped(gi, gq, 20, 7, 4, 2, dp2,
+                                              r.count - 1, dm)
+    assert not grouped and r2.count == r.count     # no room: nothing grouped
+    r3, grouped = V.findmumcandidates_grouped(gi, gq, 20, 7, 4, 2, dp2,
+                                              r.count + 4, dm)
+    rows3, meta = np.zeros_like(rows), np.zeros(8, np.uint64)
+    V.device_download(rows3, dp2)
+    V.device_download(meta, dm)
+    assert grouped and r3.count == r.count
+    assert np.array_equal(meta[:4], counts) and np.array_equal(meta[4:], top)
+    part = lambda x: (S.unpack_candidates(x, 7, V.MATCH_DTYPE)["dbstart"]
+                      * np.uint64(4)) // np.uint64(idx.n + 1)
+    assert np.array_equal(part(rows3), part(rows))
+    assert np.array_equal(rows3[np.lexsort((rows3[:, 1], rows3[:, 0]))],
+                          rows[np.lexsort((rows[:, 1], rows[:, 0]))])
+    for x in (dp, dp2, dm):
+        V.device_free(x)
     with pytest.raises(V.VsaError):
         V.findmumcandidates_packed(gi, gq, 20, 5)   # 100 bp need 7 bits
 

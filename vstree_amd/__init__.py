@@ -152,6 +152,7 @@ def _load():
         "vsa_findmumcandidates": (I, [V, V, U64, I, PP]),
         "vsa_result_partition": (I, [V, U32, U64, V, V, V]),
         "vsa_result_partition_own": (I, [V, U32, I, U64, V, V, V]),
+        "vsa_result_partition_device": (I, [V, U32, I, U64, V, V]),
         "vsa_findmaximaluniquematches": (I, [V, U64, PP]),
         "vsa_findmaximaluniquematches_range": (I, [V, U64, U64, U64, PP]),
         "vsa_findmaximalrepeats": (I, [V, U64, PP]),
@@ -160,6 +161,8 @@ def _load():
         "vsa_findsupermaximalrepeats_cb": (I, [V, U64, PROCESSMATCH, V]),
         "vsa_findtandems": (I, [V, U64, PP]),
         "vsa_findmumcandidates_packed": (I, [V, V, U64, C.c_uint32, PP]),
+        "vsa_findmumcandidates_grouped": (
+            I, [V, V, U64, C.c_uint32, U32, I, V, U64, V, PP]),
         "vsa_result_packbits": (C.c_uint32, [V]),
         "vsa_mumuniqueinquery_range_packed": (
             I, [V, U64, C.c_uint32, U64, I, U64, PP]),
@@ -382,6 +385,15 @@ class Result:
                                             _ptr(counts), _ptr(maxright)))
         return counts, maxright
 
+    def partition_device(self, nparts, totallength, device_ptr, device_meta,
+                         own=-1):
+        """partition() that leaves (counts, largest right ends) in device
+        memory at device_meta (2*nparts uint64) and does not wait for the
+        GPU"""
+        _check(lib.vsa_result_partition_device(
+            self._h, int(nparts), int(own), int(totallength), device_ptr,
+            device_meta))
+
     @property
     def packbits(self):
         """length bits of a packed candidate result, 0 for records"""
@@ -472,6 +484,22 @@ def findmumcandidates_packed(index, queries, searchlength, lengthbits=0):
                                             int(searchlength),
                                             int(lengthbits), C.byref(h)))
     return Result(h)
+
+
+def findmumcandidates_grouped(index, queries, searchlength, lengthbits,
+                              nparts, own, device_rows, capacity,
+                              device_meta):
+    """findmumcandidates_packed + Result.partition_device in one call ->
+    (result, grouped): grouped False = more than `capacity` rows, nothing
+    was written to device_rows"""
+    h = C.c_void_p()
+    rc = lib.vsa_findmumcandidates_grouped(
+        index._h, queries._h, int(searchlength), int(lengthbits),
+        int(nparts), int(own), device_rows, int(capacity), device_meta,
+        C.byref(h))
+    if rc not in (0, 1):
+        _check(rc)
+    return Result(h), rc == 0
 
 
 def findmaximalrepeats(index, searchlength):

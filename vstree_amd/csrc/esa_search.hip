@@ -2920,13 +2920,69 @@ k_partition_place_small(const PartInput in, uint64_t n, uint32_t nparts,
   }
 }
 
+// counts[p], maxright[p] by part from the summary by place in the output
+__global__ void __launch_bounds__(VSA_PART_MAX)
+k_partition_meta(const uint64_t *__restrict__ summary, uint32_t nparts,
+                 uint32_t own, uint64_t *__restrict__ meta)
+{
+  const uint32_t p = threadIdx.x;
+  if (p < nparts)
+  {
+    const uint32_t at = p < own ? p : (p == own ? nparts - 1 : p - 1);
+    meta[p] = summary[at + 1] - summary[at];
+    meta[nparts + p] = summary[VSA_PART_MAX + 1 + at];
+  }
+}
+
+namespace
+{
+
+int partition_impl(const vsa_result *result, uint32_t nparts, int ownpart,
+                   uint64_t totallength, void *device_matches,
+                   uint64_t *counts, uint64_t *maxright,
+                   uint64_t *device_meta);
+
+} // namespace
+
 extern "C" int vsa_result_partition_own(const vsa_result *result,
                                         uint32_t nparts, int ownpart,
                                         uint64_t totallength,
                                         void *device_matches, uint64_t *counts,
                                         uint64_t *maxright)
 {
-  if (result == nullptr || counts == nullptr || nparts == 0 ||
+  if (counts == nullptr)
+  {
+    VSA_ERROR("vsa_result_partition: bad argument (counts)");
+    return -1;
+  }
+  return partition_impl(result, nparts, ownpart, totallength, device_matches,
+                        counts, maxright, nullptr);
+}
+
+extern "C" int vsa_result_partition_device(const vsa_result *result,
+                                           uint32_t nparts, int ownpart,
+                                           uint64_t totallength,
+                                           void *device_matches,
+                                           uint64_t *device_meta)
+{
+  if (device_meta == nullptr)
+  {
+    VSA_ERROR("vsa_result_partition_device: bad argument (device_meta)");
+    return -1;
+  }
+  return partition_impl(result, nparts, ownpart, totallength, device_matches,
+                        nullptr, nullptr, device_meta);
+}
+
+namespace
+{
+
+int partition_impl(const vsa_result *result, uint32_t nparts, int ownpart,
+                   uint64_t totallength, void *device_matches,
+                   uint64_t *counts, uint64_t *maxright,
+                   uint64_t *device_meta)
+{
+  if (result == nullptr || nparts == 0 ||
       nparts > VSA_PART_MAX || ownpart >= (int) nparts ||
       (result->count > 0 && device_matches == nullptr))
   {
@@ -2934,7 +2990,7 @@ extern "C" int vsa_result_partition_own(const vsa_result *result,
               "among them or < 0)");
     return -1;
   }
-  for (uint32_t p = 0; p < nparts; p++)
+  for (uint32_t p = 0; p < nparts && counts != nullptr; p++)
   {
     counts[p] = 0;
     if (maxright != nullptr)
@@ -2943,16 +2999,21 @@ extern "C" int vsa_result_partition_own(const vsa_result *result,
     }
   }
   const uint64_t n = result->count;
-  if (n == 0)
-  {
-    return 0;
-  }
   if (vsa_set_device(result->device) != 0)
   {
     return -100;
   }
   hipStream_t stream = nullptr;
   vsa_dev_set_stream(stream);
+  if (n == 0)
+  {
+    if (device_meta != nullptr)
+    {
+      VSA_HIP(hipMemsetAsync(device_meta, 0, 2 * (size_t) nparts * 8,
+                             stream));
+    }
+    return 0;
+  }
   // tiles of eight records per lane for pairs that go to up to 8 parts
   // (VSA_PARTITION_SMALL=0: the general kernels, for comparison)
   static const bool smallok = []() {
@@ -3023,6 +3084,15 @@ extern "C" int vsa_result_partition_own(const vsa_result *result,
         device_matches);
   }
   VSA_HIP(hipGetLastError());
+  if (device_meta != nullptr)
+  {
+    // the numbers stay on the device (the input of the ranks' all-gather):
+    // nothing here waits for the GPU
+    k_partition_meta<<<1, VSA_PART_MAX, 0, stream>>>(
+        summary.as<uint64_t>(), nparts, in.own, device_meta);
+    VSA_HIP(hipGetLastError());
+    return 0;
+  }
   VSA_HIP(hipMemcpyAsync(host, summary.p, (2 * VSA_PART_MAX + 1) * 8,
                          hipMemcpyDeviceToHost, stream));
   VSA_HIP(hipStreamSynchronize(stream));
@@ -3039,6 +3109,8 @@ extern "C" int vsa_result_partition_own(const vsa_result *result,
   return 0;
 }
 
+} // namespace
+
 extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
                                     uint64_t totallength,
                                     void *device_matches, uint64_t *counts,
@@ -3046,6 +3118,39 @@ extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
 {
   return vsa_result_partition_own(result, nparts, -1, totallength,
                                   device_matches, counts, maxright);
+}
+
+extern "C" int vsa_findmumcandidates_grouped(const vsa_index *index,
+                                             const vsa_queries *queries,
+                                             uint64_t searchlength,
+                                             uint32_t lengthbits,
+                                             uint32_t nparts, int ownpart,
+                                             void *device_rows,
+                                             uint64_t capacity,
+                                             uint64_t *device_meta,
+                                             vsa_result **result)
+{
+  const int rc = vsa_findmumcandidates_packed(index, queries, searchlength,
+                                              lengthbits, result);
+  if (rc != 0)
+  {
+    return rc;
+  }
+  if ((*result)->count > capacity)
+  {
+    return 1; // the caller makes room and groups the result itself
+  }
+  // no return to the caller between the search and the grouping: the GPU
+  // waits for one kernel launch, not for an interpreter
+  const int prc = vsa_result_partition_device(*result, nparts, ownpart,
+                                              index->n, device_rows,
+                                              device_meta);
+  if (prc != 0)
+  {
+    vsa_result_free(*result);
+    *result = nullptr;
+  }
+  return prc;
 }
 
 // ---- batches whose thresholds (-e Kp / -h Kp) are 0 for the short reads and

@@ -126,9 +126,16 @@ def _meta_staging(torch, world, device):
     return _META[key]
 
 
+def meta_device_buffer(torch, world, device):
+    """the device tensor (2*world int64) vsa_result_partition_device writes
+    for partitioned_mum_filter_presorted(meta_on_device=True)"""
+    return _meta_staging(torch, world, device)["dev_in"]
+
+
 def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
                                      device, filter_fn, words=MATCH_WORDS,
-                                     extra=(), reduce=True, own_last=False):
+                                     extra=(), reduce=True, own_last=False,
+                                     meta_on_device=False):
     """partitioned_mum_filter for candidates that vsa_result_partition has
     grouped by destination already (send[r] rows for rank r, maxright[r] =
     their largest right end): no sorting on this side and three collectives --
@@ -145,7 +152,11 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     (vsa_result_partition_own) and never enter the exchange: the all-to-all
     runs over the rows in front of them with a split of 0 for the rank
     itself, and filter_fn(own, received, carry) gets the two lists as they
-    lie (vsa_mumuniqueinquery_range_packed2 takes them as one)."""
+    lie (vsa_mumuniqueinquery_range_packed2 takes them as one).
+    meta_on_device=True (RCCL only): send and maxright are None -- the 2*world
+    numbers lie in meta_device_buffer(...) already, where
+    vsa_result_partition_device left them without waiting for the GPU; they
+    reach the host once, gathered."""
     world, me = dist.get_world_size(), dist.get_rank()
     rows = rows.reshape(-1, words)
     # which collectives the backend has is a property of the process group,
@@ -153,13 +164,16 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     # inside `except` would let ranks that fail for another reason issue a
     # different collective than the others)
     rccl = dist.get_backend() == "nccl"
-    if rccl and _STAGED:
+    if meta_on_device and not rccl:
+        raise ValueError("meta_on_device needs the RCCL backend")
+    if rccl and (_STAGED or meta_on_device):
         # one tensor in, one out, through page-locked staging buffers kept
         # from batch to batch: no allocation, no pageable copy
         st = _meta_staging(torch, world, device)
-        st["np_in"][:world] = send
-        st["np_in"][world:] = maxright
-        st["dev_in"].copy_(st["host_in"], non_blocking=True)
+        if not meta_on_device:
+            st["np_in"][:world] = send
+            st["np_in"][world:] = maxright
+            st["dev_in"].copy_(st["host_in"], non_blocking=True)
         dist.all_gather_into_tensor(st["dev_out"], st["dev_in"])
         st["host_out"].copy_(st["dev_out"], non_blocking=True)
         torch.cuda.current_stream().synchronize()
@@ -189,7 +203,12 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
         sends[np.arange(world), np.arange(world)] = 0
     recv = [int(x) for x in sends[:, me]]
     mine = torch.empty((sum(recv), words), dtype=torch.int64, device=device)
-    if rccl:
+    if not sends.any():
+        # nothing travels (one rank; or every candidate lies in its own
+        # rank's range): every rank sees the same table and takes this branch
+        # with the others
+        pass
+    elif rccl:
         dist.all_to_all_single(mine, rows[:nrows - nown], recv,
                                [int(x) for x in sends[me]])
     else:
