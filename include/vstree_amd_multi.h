@@ -87,6 +87,27 @@ int vsa_multi_findmatches_cb(vsa_multi *multi, int mode,
                              const uint64_t *length, uint64_t nq,
                              vsa_processmatch processmatch, void *info);
 
+/*
+  findcompletematches for approximate matching (vmatch -complete -e K | -h K,
+  vsa_findapproxcompletematches; Vmengine/approxcompl.c:138-199) over all
+  replicas: the reads are independent, every replica answers its block, the
+  lists are concatenated in block order = the reference's order; the distance
+  of a match travels in its querystart field.  VSA_NOT_COVERED (from any
+  replica) = nothing was delivered for the whole job.  The reference's
+  "threshold=...>=...=patternlen not allowed" ends the job at that read, with
+  the matches of the reads before it.
+*/
+int vsa_multi_findapproxcompletematches(
+    vsa_multi *multi, int doedist, uint64_t distvalue, int percent,
+    const uint8_t *symbols, uint64_t nsymbols, const uint64_t *start,
+    const uint64_t *length, uint64_t nq, vsa_match **matches, uint64_t *count,
+    vsa_stats *total);
+int vsa_multi_findapproxcompletematches_cb(
+    vsa_multi *multi, int doedist, uint64_t distvalue, int percent,
+    const uint8_t *symbols, uint64_t nsymbols, const uint64_t *start,
+    const uint64_t *length, uint64_t nq, vsa_processmatch processmatch,
+    void *info);
+
 #ifdef __cplusplus
 }
 #endif

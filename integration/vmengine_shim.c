@@ -434,7 +434,53 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
   {
     int devices[MAXGPUS];
     const uint32_t ndevices = multidevices(devices);
-    if (ndevices > 0 && !approx)
+    if (ndevices > 0 && approx)
+    {
+      /* the reads are independent: every replica answers a block of them
+         (vsa_multi_findapproxcompletematches) */
+      vsa_multi *multi;
+      uint64_t *start, *length;
+      Multiseq *qseq = queryinfo->multiseq;
+      Approxsink sink;
+
+      sink.matchstate = &matchstate;
+      sink.hamming = MPARMHAMMINGMATCH(&matchparam->maxdist) ? 1 : 0;
+      if (getgpumulti(virtualtree, devices, ndevices, &multi) != 0 ||
+          getquerybounds(qseq, &start, &length) != 0)
+      {
+        return (Sint) -2;
+      }
+      rc = vsa_multi_findapproxcompletematches_cb(
+          multi, MPARMEDISTMATCH(&matchparam->maxdist) ? 1 : 0,
+          (uint64_t) matchparam->maxdist.distvalue,
+          matchparam->maxdist.distinterpretation == Qualpercentaway ? 1 : 0,
+          rcmode ? qseq->rcsequence : qseq->sequence, qseq->totallength,
+          start, length, qseq->numofsequences, approxsink, &sink);
+      free(start);
+      free(length);
+      trace("approximate complete matches, all replicas");
+      if (rc == VSA_NOT_COVERED)
+      {
+        /* nothing has been reported yet: the reference's own function takes
+           the whole batch */
+        return __real_findcompletematches(
+            virtualtree, indexormatchfile, queryinfo, rcmode, online,
+            matchparam, bestflag, shownoevalue, showselfpalindromic,
+            selectbundle, procmultiseq, currentdirection, processfinal,
+            cpridxpatsearchbundle, cpridxpatsearchdata, evalues,
+            domatchbuffering);
+      }
+      if (rc != 0)
+      {
+        if (rc != -1)
+        {
+          (void) gpufail();
+        }
+        return (Sint) -2;
+      }
+      return 0;
+    }
+    if (ndevices > 0)
     {
       rc = runonallgpus(virtualtree, queryinfo->multiseq, rcmode,
                         VSA_MULTI_COMPLETE, 0, 2, devices, ndevices,

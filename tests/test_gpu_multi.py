@@ -51,6 +51,41 @@ def test_replicas_reproduce_the_reference_lists(V, MG, world):
     m.close()
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_replicas_answer_approximate_matching(V, MG, world):
+    """vmatch -complete -e K | -h K over replicas: every replica takes a
+    block of the reads, the lists in block order are the reference's list
+    (golden c1 / c6: pigeonhole path, tree path, percent thresholds); a
+    configuration one replica declines is declined for the whole job"""
+    for case in ("c1", "c6"):
+        idx, q, m = tables(MG, case, [0] * world)
+        for key in sorted(H.manifest()[case]["runs"]):
+            if not key.startswith("approx_"):
+                continue
+            spec = key[len("approx_"):]
+            doedist, k, pct = spec[0] == "e", int(spec[1:].rstrip("p")), \
+                spec.endswith("p")
+            got, st, rc, msg = m.findapproxcompletematches(
+                q.symbols, q.start, q.length, doedist, k, pct)
+            assert rc == 0, (case, key, msg)
+            want = H.expected(case, key)
+            assert np.array_equal(H.matches_as_ref(idx, got), want), \
+                (world, case, key)
+            assert st.count == len(want)
+        m.close()
+    # the reference's error ends the job at its read; the reads in front of
+    # it, also those of earlier blocks, are answered
+    idx, q, m = tables(MG, "c5", [0] * world)
+    reads = H.Queries.from_list([q.symbols[:150], q.symbols[400:550],
+                                 q.symbols[200:203], q.symbols[600:750]])
+    got, st, rc, msg = m.findapproxcompletematches(
+        reads.symbols, reads.start, reads.length, True, 3)
+    assert rc != 0 and "threshold=3>=3=patternlen not allowed" in msg
+    first = H.Queries.from_list([q.symbols[:150], q.symbols[400:550]])
+    assert np.array_equal(got, H.oracle_approx(idx, first, True, 3))
+    m.close()
+
+
 def test_one_replica_sums_its_counters_through_rccl(V, MG):
     """a communicator of one rank: the ncclAllReduce path runs for real"""
     idx, q, m = tables(MG, "micro", [0])

@@ -206,7 +206,14 @@ struct Job
   const uint64_t *start, *length;
   uint64_t nq, totallength;
   uint32_t lengthbits; // -mum: 0 = records instead of pairs
+  // VSA_MULTI_APPROX (vsa_multi_findapproxcompletematches)
+  int doedist, percent;
+  uint64_t distvalue;
 };
+
+// -complete -e K | -h K: a mode of this file only (the public modes end at
+// VSA_MULTI_MUM)
+#define VSA_MULTI_APPROX (VSA_MULTI_MUM + 1)
 
 // phase 1 of replica r: upload its block of queries, search
 void searchblock(const Job &job, uint32_t r, RankOut &o)
@@ -266,6 +273,10 @@ void searchblock(const Job &job, uint32_t r, RankOut &o)
       break;
     case VSA_MULTI_MUMCAND:
       rc = vsa_findquerymatches(m->ix[r], q, 1, 1, job.searchlength, &res);
+      break;
+    case VSA_MULTI_APPROX:
+      rc = vsa_findapproxcompletematches(m->ix[r], q, job.doedist,
+                                         job.distvalue, job.percent, &res);
       break;
     default:
       rc = job.lengthbits != 0
@@ -527,17 +538,19 @@ extern "C" void vsa_multi_free_matches(vsa_match *matches)
   free(matches);
 }
 
-extern "C" int vsa_multi_findmatches(vsa_multi *m, int mode,
-                                     uint64_t searchlength,
-                                     const uint8_t *symbols, uint64_t nsymbols,
-                                     const uint64_t *start,
-                                     const uint64_t *length, uint64_t nq,
-                                     vsa_match **matches, uint64_t *count,
-                                     vsa_stats *total)
+namespace
+{
+
+int multi_findmatches(vsa_multi *m, int mode, uint64_t searchlength,
+                      int doedist, uint64_t distvalue, int percent,
+                      const uint8_t *symbols, uint64_t nsymbols,
+                      const uint64_t *start, const uint64_t *length,
+                      uint64_t nq, vsa_match **matches, uint64_t *count,
+                      vsa_stats *total)
 {
   if (m == nullptr || matches == nullptr || count == nullptr || mode < 0 ||
-      mode > VSA_MULTI_MUM || (nq > 0 && (start == nullptr ||
-                                          length == nullptr)) ||
+      mode > VSA_MULTI_APPROX || (nq > 0 && (start == nullptr ||
+                                             length == nullptr)) ||
       (nsymbols > 0 && symbols == nullptr))
   {
     seterror("vsa_multi_findmatches: bad argument");
@@ -578,6 +591,9 @@ extern "C" int vsa_multi_findmatches(vsa_multi *m, int mode,
   job.nq = nq;
   job.totallength = info.totallength;
   job.lengthbits = 0;
+  job.doedist = doedist;
+  job.distvalue = distvalue;
+  job.percent = percent;
   if (mode == VSA_MULTI_MUM)
   {
     // the pairs of all replicas are laid out alike: the length bits of the
@@ -598,6 +614,16 @@ extern "C" int vsa_multi_findmatches(vsa_multi *m, int mode,
   onallreplicas(world, [&](uint32_t r) { searchblock(job, r, out[r]); });
   int rc = 0;
   uint32_t failed = world;
+  for (uint32_t r = 0; r < world; r++)
+  {
+    // a configuration the engine does not take: of the whole job, nothing is
+    // delivered (the caller hands all of it to the reference's own function)
+    if (out[r].rc == VSA_NOT_COVERED)
+    {
+      seterror(out[r].message);
+      return VSA_NOT_COVERED;
+    }
+  }
   for (uint32_t r = 0; r < world; r++)
   {
     if (out[r].rc != 0)
@@ -671,6 +697,64 @@ extern "C" int vsa_multi_findmatches(vsa_multi *m, int mode,
   {
     rc = reducecounters(m, *lists, total);
   }
+  return rc;
+}
+
+} // namespace
+
+extern "C" int vsa_multi_findmatches(vsa_multi *m, int mode,
+                                     uint64_t searchlength,
+                                     const uint8_t *symbols, uint64_t nsymbols,
+                                     const uint64_t *start,
+                                     const uint64_t *length, uint64_t nq,
+                                     vsa_match **matches, uint64_t *count,
+                                     vsa_stats *total)
+{
+  if (mode > VSA_MULTI_MUM)
+  {
+    seterror("vsa_multi_findmatches: bad argument");
+    return -1;
+  }
+  return multi_findmatches(m, mode, searchlength, 0, 0, 0, symbols, nsymbols,
+                           start, length, nq, matches, count, total);
+}
+
+extern "C" int vsa_multi_findapproxcompletematches(
+    vsa_multi *m, int doedist, uint64_t distvalue, int percent,
+    const uint8_t *symbols, uint64_t nsymbols, const uint64_t *start,
+    const uint64_t *length, uint64_t nq, vsa_match **matches, uint64_t *count,
+    vsa_stats *total)
+{
+  return multi_findmatches(m, VSA_MULTI_APPROX, 0, doedist, distvalue,
+                           percent, symbols, nsymbols, start, length, nq,
+                           matches, count, total);
+}
+
+extern "C" int vsa_multi_findapproxcompletematches_cb(
+    vsa_multi *m, int doedist, uint64_t distvalue, int percent,
+    const uint8_t *symbols, uint64_t nsymbols, const uint64_t *start,
+    const uint64_t *length, uint64_t nq, vsa_processmatch processmatch,
+    void *info)
+{
+  vsa_match *matches = nullptr;
+  uint64_t count = 0;
+  if (processmatch == nullptr)
+  {
+    seterror("vsa_multi_findapproxcompletematches_cb: NULL callback");
+    return -1;
+  }
+  int rc = vsa_multi_findapproxcompletematches(
+      m, doedist, distvalue, percent, symbols, nsymbols, start, length, nq,
+      &matches, &count, nullptr);
+  for (uint64_t i = 0; i < count; i++)
+  {
+    if (processmatch(info, matches + i) != 0)
+    {
+      rc = -1; // stopped by the callback, like the single-GPU entries
+      break;
+    }
+  }
+  vsa_multi_free_matches(matches);
   return rc;
 }
 

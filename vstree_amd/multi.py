@@ -27,6 +27,11 @@ SIGNATURES = {
     "vsa_multi_free_matches": (None, [_V]),
     "vsa_multi_findmatches_cb": (_I, [_V, _I, _U64, _V, _U64, _V, _V, _U64,
                                       V.PROCESSMATCH, _V]),
+    "vsa_multi_findapproxcompletematches": (
+        _I, [_V, _I, _U64, _I, _V, _U64, _V, _V, _U64, _PP, C.POINTER(_U64),
+             C.POINTER(V.Stats)]),
+    "vsa_multi_findapproxcompletematches_cb": (
+        _I, [_V, _I, _U64, _I, _V, _U64, _V, _V, _U64, V.PROCESSMATCH, _V]),
 }
 
 
@@ -100,6 +105,24 @@ class Multi:
             self._h, int(mode), int(searchlength), V._ptr(symbols),
             symbols.shape[0], V._ptr(start), V._ptr(length), start.shape[0],
             C.byref(out), C.byref(n), C.byref(st))
+        m = np.zeros(n.value, MATCH_DTYPE)
+        if n.value:
+            C.memmove(m.ctypes.data, out.value, n.value * 32)
+        lib.vsa_multi_free_matches(out)
+        return m, st, rc, V.messagespace() if rc != 0 else ""
+
+    def findapproxcompletematches(self, symbols, start, length, doedist,
+                                  distvalue, percent=False):
+        """vmatch -complete -e K | -h K over all replicas -> (matches, Stats,
+        rc, message); the distance of a match in its querystart field"""
+        symbols = np.ascontiguousarray(symbols, np.uint8)
+        start = np.ascontiguousarray(start, np.uint64)
+        length = np.ascontiguousarray(length, np.uint64)
+        out, n, st = C.c_void_p(), C.c_uint64(), V.Stats()
+        rc = lib.vsa_multi_findapproxcompletematches(
+            self._h, int(doedist), int(distvalue), int(percent),
+            V._ptr(symbols), symbols.shape[0], V._ptr(start), V._ptr(length),
+            start.shape[0], C.byref(out), C.byref(n), C.byref(st))
         m = np.zeros(n.value, MATCH_DTYPE)
         if n.value:
             C.memmove(m.ctypes.data, out.value, n.value * 32)
