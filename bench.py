@@ -887,9 +887,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": sb / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "HBM bytes of ALL kernels of one step (PMC FETCH_SIZE "
-                        "+ WRITE_SIZE of a run with two steps minus a run "
-                        "with one, %s) / ms_per_step of this run"
-                        % tj.get("source")}
+                        "+ WRITE_SIZE of every dispatch between the first "
+                        "pass of one step and the first pass of the next, "
+                        "%s) / ms_per_step of this run" % tj.get("source")}
         sys.stdout.flush()
         os.write(jsonfd, (json.dumps(out) + "\n").encode())
     if distributed:
