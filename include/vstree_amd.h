@@ -357,11 +357,19 @@ int vsa_findmumcandidates_grouped(const vsa_index *index,
   path (a depth-first walk of the lcp-interval tree per piece,
   approx_tree.inc) instead of the pigeonhole path; a batch with ONE such
   query takes it as a whole.
+  Reads whose threshold is 0 (-e Kp / -h Kp on short reads) are exact
+  searches (approxcompl.c:167-176), also inside a batch whose other reads
+  have thresholds > 0: the batch is cut into the two kinds and the lists are
+  merged back into query order; the first read the reference would stop at
+  (shorter than prefixlength with threshold 0, or threshold >= length) ends
+  the run with its message, -2, and the matches of the reads before it.
+  Text positions are kept in the width of the index tables: texts of 2^32
+  symbols and more are searched like the others.
   VSA_NOT_COVERED (-4), no result: the configuration is one this engine does
-  not implement (alphabets beyond 4 symbols; m > 256; a batch mixing
-  thresholds 0 and > 0; texts of 2^32 symbols or more) -- the caller keeps
-  using its CPU function for such batches (integration/vmengine_shim.c
-  does).
+  not implement (alphabets other than 4 symbols; a read of more than 512
+  symbols; a batch of 2^31 reads and more, or more reads than
+  bits(reads) + bits(text length) <= 64 allows) -- the caller keeps using its
+  CPU function for such batches (integration/vmengine_shim.c does).
 */
 #define VSA_NOT_COVERED (-4)
 int vsa_findapproxcompletematches(const vsa_index *index,
