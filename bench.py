@@ -55,6 +55,31 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def human(x, unit=""):
+    """3e9 -> '3 G', 1e7 -> '10 M', 150000 -> '150 k' (exact sizes stand next
+    to the label in the config, so rounding here hides nothing)"""
+    for f, s in ((1e9, "G"), (1e6, "M"), (1e3, "k")):
+        if x >= f:
+            v = x / f
+            return ("%d %s%s" % (round(v), s, unit) if abs(v - round(v)) < 1e-9
+                    else "%.3g %s%s" % (v, s, unit))
+    return "%d %s" % (x, unit)
+
+
+def workload_label(n, nq, m, L, mode, tail=""):
+    """what this run searched, from the sizes it ran with -- a line cannot
+    claim another configuration than the one its arguments gave it"""
+    return ("%s synthetic DNA index, %s x %d bp queries per GPU, %s -l %d%s"
+            % (human(n, "bp"), human(nq), m, mode, L, tail))
+
+
+def baseline_config(n, nq, m, L):
+    """which BASELINE.json config these sizes are, if any"""
+    if (n, nq, m, L) == (3000000000, 10000000, 100, 20):
+        return "BASELINE.json configs[2] (configs[3] sharding for N > 1)"
+    return "not a BASELINE.json configuration (sizes given on the command line)"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +116,14 @@ def parse():
     # libvstree_amd_multi.so (vsa_multi_findmatches: a host thread per GPU,
     # peer copies for the -mum exchange, ncclAllReduce of the counters) -- the
     # path the drop-in binary takes (VMATCH_GPUS=N)
-    ap.add_argument("--path", choices=("torch", "c"), default="torch")
+    ap.add_argument("--path", choices=("torch", "c"), default=None,
+                    help="N > 1 (default c): c = one process, a host thread "
+                         "per GPU (libvstree_amd_multi.so); torch = one "
+                         "process per GPU over torch.distributed")
+    ap.add_argument("--host", action="store_true",
+                    help="--path c: time the host-memory entry "
+                         "(vsa_multi_findmatches) instead of the "
+                         "device-resident one")
     # --path c on a box with one GPU: N replicas of the index on device 0
     ap.add_argument("--replicas-on-one-gpu", action="store_true")
     return ap.parse_args()
@@ -362,16 +394,31 @@ def launch_ranks(a, jsonfd):
     os.write(jsonfd, (line + "\n").encode())
 
 
-def c_path_mode(a, jsonfd):
-    """--path c: the product's own N > 1 path.  ONE process; vsa_multi_* drives
-    every GPU from a host thread of its own (libvstree_amd_multi.so, what
-    integration/vmengine_shim.c binds for VMATCH_GPUS=N): index replicated
-    device to device, the queries of a call cut into one block per GPU,
-    -mum candidates exchanged by peer copies and filtered per range, counters
-    through one ncclAllReduce.  The entry point takes queries in HOST memory
-    and returns the matches in HOST memory (the reference's Multiseq in,
-    processfinal out), so this line is PCIe-inclusive by construction and is
-    named accordingly; it is not the headline metric."""
+def c_path_mode(a, jsonfd, rank, world):
+    """--path c (the default for N > 1): the product's own N > 1 path.  ONE
+    process drives every GPU through libvstree_amd_multi.so, a host thread per
+    GPU (what integration/vmengine_shim.c binds for VMATCH_GPUS=N): the index
+    replicated device to device, every replica's block of queries resident in
+    ITS HBM before the clock starts, the lists left in HBM
+    (vsa_multi_findmatches_device); -mum candidates cross between GPUs as
+    16-byte rows by peer copies, the counters take the one ncclAllReduce.
+    `--host` times the host-memory entry instead (vsa_multi_findmatches:
+    queries in host memory, matches back in host memory -- PCIe-inclusive,
+    named so in the metric, never the headline).
+    Under a launcher with N ranks (the driver's command line) rank 0 is that
+    one process; the other ranks hold no GPU and meet it at the barriers."""
+    dist = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank != 0:
+        dist.barrier()      # setup done
+        dist.barrier()      # timed region over
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     import vstree_amd as V
     from vstree_amd import multi as M
     n, nq, m, L = int(a.genome), int(a.queries), a.qlen, a.minlen
@@ -385,69 +432,132 @@ def c_path_mode(a, jsonfd):
             sys.exit(2)
         devices = list(range(N))
     t0 = time.time()
-    dg = V.device_malloc(n + 64, 0)
-    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, n, dg, 0))
-    index = V.Index.build_device(dg, n, 4, 0, 0)
+    dg = V.device_malloc(n + 64, devices[0])
+    V._check(V.lib.vsa_synth_genome_device(V.GENOME_SEED, n, dg, devices[0]))
+    index = V.Index.build_device(dg, n, 4, 0, devices[0])
     info = index.info()
-    # the queries of the whole job in host memory, as a reference caller
-    # holds them
+    t_index = time.time() - t0
+    # the queries of the whole job: block r of nq reads for replica r (weak
+    # scaling), generated on the first device
     pos, sub, step = V.synth_query_plan(n, nq * N, m)
-    hq = np.empty(nq * N * m, np.uint8)
-    dq = V.device_malloc(nq * m + 64, 0)
+    dq = V.device_malloc(nq * m + 64, devices[0])
+    hq = np.empty(nq * N * m, np.uint8) if a.host else None
+    blocks, hblock = [], np.empty(nq * m, np.uint8)
     for r in range(N):
         sl = slice(r * nq, (r + 1) * nq)
         ps, sb, st = (np.ascontiguousarray(x[sl]) for x in (pos, sub, step))
         V._check(V.lib.vsa_synth_queries_device(
             dg, n, ps.ctypes.data, sb.ctypes.data, st.ctypes.data, nq, m, dq,
-            0))
-        V.device_download(hq[r * nq * m:(r + 1) * nq * m], dq, 0)
-    V.device_free(dq, 0)
-    V.device_free(dg, 0)
+            devices[0]))
+        if a.host:
+            V.device_download(hq[r * nq * m:(r + 1) * nq * m], dq, devices[0])
+        elif devices[r] == devices[0]:
+            b = V.Queries.from_device(dq, nq, m, devices[r])
+            b.set_offset(r * nq)
+            blocks.append(b)
+        else:
+            V.device_download(hblock, dq, devices[0])
+            b = V.Queries.from_host(hblock, np.arange(nq, dtype=np.uint64) * m,
+                                    np.full(nq, m, np.uint64), devices[r])
+            b.set_offset(r * nq)
+            blocks.append(b)
+    V.device_free(dq, devices[0])
+    V.device_free(dg, devices[0])
     t1 = time.time()
     multi = M.Multi.replicate(index, devices)
     t_rep = time.time() - t1
-    log("setup: index %d bp built in %.1fs, %d replica(s) in %.1fs"
-        % (n, t1 - t0, N, t_rep))
+    log("setup: index %d bp (%.1f GB in HBM, deep prefix %d) built in %.1fs, "
+        "%d replica(s) in %.1fs" % (n, info.device_bytes / 1e9,
+                                    info.deepprefix, t_index, N, t_rep))
     start = np.arange(nq * N, dtype=np.uint64) * m
     length = np.full(nq * N, m, np.uint64)
+    kernel_ms, first_ms = [], []
+
+    def one_step():
+        if a.host:
+            mm, st, rc, msg = multi.findmatches(M.MUM, hq, start, length, L)
+        else:
+            res, st, rc, msg = multi.findmatches_device(M.MUM, blocks, L)
+            for r_ in res:
+                if r_ is not None:
+                    r_.close()
+        if rc != 0:
+            raise RuntimeError(msg)
+        kernel_ms.append(st.search_kernel_ms)
+        first_ms.append(st.first_kernel_ms)
+        return st
+
+    def sync():
+        for d in sorted(set(devices)):
+            V.device_synchronize(d)
+        if dist is not None:
+            dist.barrier()
+
     st = None
     for _ in range(a.warmup):
-        mm, st, rc, msg = multi.findmatches(M.MUM, hq, start, length, L)
-        if rc != 0:
-            raise RuntimeError(msg)
+        st = one_step()
+    kernel_ms.clear()
+    first_ms.clear()
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        mm, st, rc, msg = multi.findmatches(M.MUM, hq, start, length, L)
-        if rc != 0:
-            raise RuntimeError(msg)
+        st = one_step()
+    sync()
     elapsed = time.perf_counter() - t0
+    kms = float(np.mean(kernel_ms))
+    what = ("host memory to host memory through vsa_multi_findmatches -- "
+            "PCIe-inclusive" if a.host else
+            "queries and match lists resident in HBM, "
+            "vsa_multi_findmatches_device")
     out = {
-        "metric": "queries/sec, host memory to host memory through "
-                  "vsa_multi_findmatches (100 bp queries, vmatch -mum -l 20, "
-                  "3 Gbp ESA index replicated in HBM) -- PCIe-inclusive, one "
-                  "process, one host thread per GPU",
+        "metric": ("queries/sec (%d bp queries, vmatch -mum -l %d semantics, "
+                   "%s ESA index replicated in HBM%s)"
+                   % (m, L, human(n, "bp"),
+                      "; host memory to host memory, PCIe-inclusive"
+                      if a.host else "")),
         "value": nq * N * a.steps / elapsed, "unit": "queries/s",
         "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "3 Gbp synthetic DNA index, 10 M x 100 bp "
-                               "queries per GPU in host memory, -mum -l 20, "
-                               "C entry point of the N > 1 path",
+        "config": {"workload": workload_label(n, nq, m, L, "-mum"),
+                   "baseline_config": baseline_config(n, nq, m, L),
+                   "path": "c: one process, a host thread per GPU (" + what +
+                           ")",
                    "index_bp": n, "queries_per_gpu": nq, "query_len": m,
-                   "minlen": L, "devices": devices,
+                   "minlen": L, "prefixlength": info.prefixlength,
+                   "deepprefix": info.deepprefix,
+                   "index_bytes_hbm": info.device_bytes,
+                   "index_build_s": round(t_index, 2),
+                   "devices": devices,
                    "replicas_on_one_gpu": bool(a.replicas_on_one_gpu),
                    "index_replication_s": round(t_rep, 2),
-                   "parallelism": "index replicated, queries in %d blocks"
-                                  % N},
-        "rccl_ranks": N if multi.uses_rccl() else 0,
+                   "parallelism": "index replicated, queries in %d blocks, "
+                                  "-mum candidates exchanged by peer copies, "
+                                  "counters by one ncclAllReduce" % N},
+        "gbp_matched_per_s": st.sumlength / (elapsed / a.steps) / 1e9,
+        "rccl_ranks": N if multi.uses_rccl() else 0, "ranks": 1,
+        "launcher_ranks": world,
         "matches": int(st.count), "candidates": int(st.candidates),
         "query_suffix_searches": int(st.searches),
-        "bytes_over_pcie_per_step": int(nq * N * m + 16 * nq * N +
-                                        32 * int(st.count)),
+        # the dominant kernel on the slowest replica (HIP events); its
+        # algorithmic bytes are counted at N = 1 by the single-process line
+        "roofline": {"kernel": "k_query_search_planned<256>", "bound": "hbm",
+                     "kernel_ms": kms, "first_pass_ms": float(np.mean(first_ms)),
+                     "searches_per_launch": int(st.kernel_searches) / N,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "achieved": None, "frac": None, "traffic": None,
+                     "note": "slowest replica per step; bytes per search are "
+                             "counted by the N = 1 line of the same sources"},
     }
+    if a.host:
+        out["bytes_over_pcie_per_step"] = int(nq * N * m + 16 * nq * N +
+                                              32 * int(st.count))
     multi.close()
     os.write(jsonfd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def physical_cores():
@@ -487,6 +597,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.path is None:
+        # N > 1: the C path (north_star: host code in C, RCCL for the count
+        # reduction); the rehearsal switches belong to the torch form
+        a.path = "c" if (a.gpus > 1 and a.mode == "mum" and
+                         not a.rehearse_on_one_gpu and
+                         not a.force_distributed) else "torch"
+    if a.path == "c" and world not in (1, a.gpus):
+        log("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a line "
+            "for another number of GPUs than asked for" % (a.gpus, world))
+        sys.exit(2)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.path == "torch":
         # started directly: become the launcher of N ranks (one per GPU) before
         # anything touches a GPU, hand their one JSON line on, leave with
@@ -498,7 +618,7 @@ def main():
         sys.exit(2)
     dev = 0 if a.rehearse_on_one_gpu else local_rank
     if a.path == "c":
-        return c_path_mode(a, jsonfd)
+        return c_path_mode(a, jsonfd, rank, world)
 
     torch = dist = S = None
     distributed = world > 1 or a.force_distributed
@@ -683,17 +803,16 @@ def main():
     fms = float(np.mean(first_ms)) if first_ms else float("nan")
 
     out = {
-        "metric": "queries/sec (100 bp queries, vmatch -mum -l 20 "
-                  "semantics, 3 Gbp ESA index resident in HBM)",
+        "metric": "queries/sec (%d bp queries, vmatch -mum -l %d "
+                  "semantics, %s ESA index resident in HBM)"
+                  % (m, L, human(n, "bp")),
         "value": qps, "unit": "queries/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "3 Gbp synthetic DNA index, 10 M x 100 bp "
-                               "queries per GPU, -mum -l 20 "
-                               "(BASELINE.json configs[2]; configs[3] "
-                               "sharding for N > 1)",
+        "config": {"workload": workload_label(n, nq, m, L, "-mum"),
+                   "baseline_config": baseline_config(n, nq, m, L),
                    "index_bp": n, "queries_per_gpu": nq, "query_len": m,
                    "minlen": L, "prefixlength": info.prefixlength,
                    "index_bytes_hbm": info.device_bytes,
@@ -878,6 +997,13 @@ def main():
                                    "peak", "unit", "frac", "traffic",
                                    "kernel_ms", "algorithmic_bytes_per_launch",
                                    "note") if k in k3}
+            # ... and as scalars: a record that keeps only the flat keys of
+            # `roofline` (BENCH_r03.json.parsed dropped the nested dict)
+            out["roofline"]["suftab_scan_frac"] = k3["frac"]
+            out["roofline"]["suftab_scan_ms"] = k3["kernel_ms"]
+            out["roofline"]["suftab_scan_bytes"] = \
+                k3["algorithmic_bytes_per_launch"]
+            out["roofline"]["suftab_scan_achieved_GBs"] = k3["achieved"]
         tj = pmc_traffic(n, nq)
         if tj.get("step_hbm_bytes"):
             sb = tj["step_hbm_bytes"]
@@ -914,7 +1040,7 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
     s = best(lambda: V.findcompletematches(index, queries))
     fams.append(family(
         "k_complete_search<uint32_t, deep>", "-complete (BASELINE configs[1] "
-        "semantics on the 3 Gbp index)", s.search_kernel_ms, cbytes * nq,
+        "semantics on the %s index)" % human(host.n, "bp"), s.search_kernel_ms, cbytes * nq,
         "bytes = %.0f B/query (SURVEY 8d: m + 2w + probes*(w + c) + lcp + "
         "occ*(w + 16))" % cbytes, traffic_key="k_complete_search", queries=nq,
         matches=s.count, call_device_ms=s.total_device_ms))
@@ -935,15 +1061,16 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
                             piece.nq, w, int(piece.length.sum()))
     fams.append(family(
         "k_complete_search<uint32_t, deep> (pieces)",
-        "-complete -e 2, 10 M x 150 bp (BASELINE configs[4]): piece search",
+        "-complete -e 2, %s x 150 bp (BASELINE configs[4] semantics): piece "
+        "search" % human(nq),
         s.search_kernel_ms, pbytes * s.searches,
         "%d pieces of 30 bp, %.0f B each" % (s.searches, pbytes),
         queries=nq, matches=s.count, call_device_ms=s.total_device_ms))
     band = 150 + 2 * 2 + 150   # text window + pattern per start position
     fams.append(family(
         "k_apm_banded<2>",
-        "-complete -e 2, 10 M x 150 bp: banded alignment of the start "
-        "positions", s.first_kernel_ms, float(band) * s.kernel_searches,
+        "-complete -e 2, %s x 150 bp: banded alignment of the start "
+        "positions" % human(nq), s.first_kernel_ms, float(band) * s.kernel_searches,
         "%d start positions x (154 text + 150 pattern symbols)"
         % s.kernel_searches, traffic_key="k_apm_banded", queries=nq))
     return fams
@@ -1157,7 +1284,8 @@ def selfmum_mode(a, V, S, torch, dist, rank, world, dev, jsonfd):
         nbytes = 2.0 * (last - first)
         out = {
             "metric": "suffix-array positions scanned per second (vmatch -mum "
-                      "-l 20 on an index that holds its queries, 3 Gbp)",
+                      "-l %d on an index that holds its queries, %s)"
+                      % (L, human(len(tis), "bp")),
             "value": len(tis) * a.steps / elapsed, "unit": "positions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,

@@ -196,6 +196,16 @@ void vsa_queries_free(vsa_queries *queries);
    Vmengine/initmstate.c:7-45) */
 int vsa_queries_set_offset(vsa_queries *queries, uint64_t offset);
 
+typedef struct
+{
+  uint64_t numofqueries, numofsymbols;
+  uint64_t minlength, maxlength; /* of a query; 0, 0 for an empty batch      */
+  uint64_t offset;               /* vsa_queries_set_offset                   */
+  int device;
+} vsa_queries_info;
+
+int vsa_queries_getinfo(const vsa_queries *queries, vsa_queries_info *info);
+
 /* ---- matches ---------------------------------------------------------- */
 
 /* field for field the reference's MUMcandidate (include/mumcand.h:17-23);
@@ -312,8 +322,14 @@ int vsa_result_partition_own(const vsa_result *result, uint32_t nparts,
                              uint64_t *maxright);
 /* ... with the 2 * nparts numbers -- counts[0 .. nparts-1], then
    maxright[0 .. nparts-1] -- left in DEVICE memory (device_meta), where the
-   all-gather of the ranks reads them: the call does not wait for the GPU
-   (work is queued on the device's default stream). */
+   all-gather of the ranks reads them: the call does not wait for the GPU.
+   STREAM CONTRACT: the work is queued on the device's default (NULL) stream
+   and nothing else orders it: whoever reads device_matches / device_meta does
+   so on that stream (a copy or collective queued there), or synchronises
+   with it first (hipStreamSynchronize(NULL) / an event recorded there).  A
+   non-blocking stream of the caller's is NOT ordered behind it.  The same
+   holds for the rows vsa_mumuniqueinquery_range_packed[2] reads: they must
+   be complete on the default stream's terms when the call is made. */
 int vsa_result_partition_device(const vsa_result *result, uint32_t nparts,
                                 int ownpart, uint64_t totallength,
                                 void *device_matches, uint64_t *device_meta);

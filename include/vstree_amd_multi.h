@@ -79,6 +79,31 @@ int vsa_multi_findmatches(vsa_multi *multi, int mode, uint64_t searchlength,
                           vsa_stats *total);
 void vsa_multi_free_matches(vsa_match *matches);
 
+/*
+  The same engine call on queries that already lie in HBM, with the lists left
+  there: blocks[r] = the block of replica r, a vsa_queries on ITS device whose
+  vsa_queries_set_offset is the number of its first query in the job (blocks
+  in ascending query order, like the split of vsa_multi_findmatches);
+  results[r] (ndevices entries, the caller frees them) = the list of replica
+  r in its HBM.  -complete, -l, -mum cand: the lists in replica order are the
+  reference's list (Vmengine/fcomplete.c:313-319, Vmengine/fquery.c:468-475).
+  -mum: results[r] holds the MUMs whose dbstart lies in range r of the index,
+  ascending; in replica order: the reference's list (kurtz/cleanMUMcand.c:55-118
+  over the candidates of all replicas -- rows of 16 bytes, range r of every
+  replica pulled to GPU r by peer copies, filtered there with the largest right
+  end of the ranges below it).  Nothing crosses PCIe but the split sizes of
+  that exchange (2 * ndevices words per replica) and the four counters, which
+  take the one ncclAllReduce when every replica has a GPU of its own.  total:
+  the counters of the whole job.  On an error the lists in front of the
+  failing replica stay (NULL behind it; a -mum job that failed has none).
+  -mum here takes queries below 65 535 symbols and query numbers below 2^47
+  (-2 otherwise: vsa_multi_findmatches handles such jobs through records).
+*/
+int vsa_multi_findmatches_device(vsa_multi *multi, int mode,
+                                 uint64_t searchlength,
+                                 vsa_queries *const *blocks,
+                                 vsa_result **results, vsa_stats *total);
+
 /* the same with the reference's delivery model: callbacks on the calling
    thread, in reference order, stop on a non-zero return */
 int vsa_multi_findmatches_cb(vsa_multi *multi, int mode,

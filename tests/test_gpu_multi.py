@@ -86,6 +86,85 @@ def test_replicas_answer_approximate_matching(V, MG, world):
     m.close()
 
 
+def device_blocks(V, q, world):
+    """the queries of a case cut into `world` contiguous blocks (the split of
+    vsa_multi_findmatches), each uploaded to device 0 with its global offset"""
+    blocks, base, extra = [], q.nq // world, q.nq % world
+    for r in range(world):
+        first = r * base + min(r, extra)
+        count = base + (1 if r < extra else 0)
+        st, ln = q.start[first:first + count], q.length[first:first + count]
+        lo = int(st.min()) if count else 0
+        hi = int((st + ln).max()) if count else 0
+        b = V.Queries.from_host(q.symbols[lo:hi], st - lo, ln, 0)
+        b.set_offset(first)
+        blocks.append(b)
+    return blocks
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_device_resident_blocks_reproduce_the_reference_lists(V, MG, world):
+    """vsa_multi_findmatches_device: the blocks lie in HBM, the lists stay
+    there; in replica order they are the reference's list, for -mum each
+    replica holds the MUMs of its range of the index"""
+    idx, q, m = tables(MG, "c1", [0] * world)
+    blocks = device_blocks(V, q, world)
+    for mode, key, L in ((MG.COMPLETE, "complete", 0),
+                         (MG.MUMCAND, "mumcand20", 20), (MG.MUM, "mum20", 20),
+                         (MG.MEM, "mem20_sp2", 20), (MG.MUM, "mum20", 20)):
+        res, st, rc, msg = m.findmatches_device(mode, blocks, L)
+        assert rc == 0, msg
+        assert all(r is not None for r in res)
+        lists = [r.fetch() for r in res]
+        got = np.concatenate(lists)
+        want = H.expected("c1", key)
+        assert np.array_equal(H.matches_as_ref(idx, got), want), (world, key)
+        assert st.count == len(want) == sum(r.count for r in res)
+        assert st.sumlength == int(want["length"].sum())
+        if mode == MG.MUM:
+            assert st.candidates == len(H.expected("c1", "mumcand20"))
+            # replica r holds range r: floor(dbstart * world / (n + 1)) == r
+            for r, l in enumerate(lists):
+                part = (l["dbstart"].astype(object) * world) // (idx.n + 1)
+                assert all(p == r for p in part)
+        for r in res:
+            r.close()
+    assert m.uses_rccl() == (world == 1)
+    # a block on the wrong device / a missing block is refused
+    res, st, rc, msg = m.findmatches_device(MG.COMPLETE, blocks, 0)
+    assert rc == 0
+    for r in res:
+        r.close()
+    m.close()
+
+
+def test_device_form_errors_follow_the_reference(V, MG):
+    idx, _, m = tables(MG, "grumbach", [0, 0, 0])
+    q = H.fasta_queries(H.os.path.join(H.GOLDEN, "short.fna"))
+    blocks = device_blocks(V, q, 3)
+    res, st, rc, msg = m.findmatches_device(MG.COMPLETE, blocks, 0)
+    assert rc < 0 and msg == "patternlength=5 must be >= 6=prefixlen"
+    got = np.concatenate([r.fetch() for r in res if r is not None])
+    assert np.array_equal(H.matches_as_ref(idx, got),
+                          H.expected("grumbach", "complete_short"))
+    res, st, rc, msg = m.findmatches_device(MG.MUM, blocks, 3)
+    assert rc < 0 and msg == "searchlength=3 must be >= 6=prefixlen"
+    assert all(r is None for r in res)
+    # ragged reads, repeats beyond 255 and wildcards through the exchange
+    m.close()
+    idx, q, m = tables(MG, "largepat", [0, 0, 0])
+    blocks = device_blocks(V, q, 3)
+    pl = idx.prefixlength
+    for mode, kw in ((MG.MEM, {}), (MG.MUMCAND, dict(mum=True, cand=True)),
+                     (MG.MUM, dict(mum=True))):
+        res, st, rc, msg = m.findmatches_device(mode, blocks, pl + 6)
+        assert rc == 0, msg
+        got = np.concatenate([r.fetch() for r in res])
+        assert np.array_equal(
+            got, H.oracle_querymatches(idx, q, pl + 6, speedup=2, **kw)), mode
+    m.close()
+
+
 def test_one_replica_sums_its_counters_through_rccl(V, MG):
     """a communicator of one rank: the ncclAllReduce path runs for real"""
     idx, q, m = tables(MG, "micro", [0])
@@ -234,28 +313,37 @@ def test_bench_started_directly_with_two_gpus_launches_two_ranks():
 
 
 def test_bench_c_path_with_replicas_on_one_gpu():
-    """--path c: vsa_multi_findmatches (the product's N > 1 entry) timed from
-    one process, here with two replicas on device 0; counters = one GPU's."""
+    """`bench.py --gpus 2` takes the product's N > 1 entry by default (--path
+    c: vsa_multi_findmatches_device from one process), here with two replicas
+    on device 0; `--host` times vsa_multi_findmatches instead; counters = one
+    GPU's on the same queries."""
     import json
     import subprocess
     import sys
     bench = H.os.path.join(H.ROOT, "bench.py")
     common = ["--genome", "3e7", "--steps", "2", "--warmup", "1", "--quick",
               "--cpu-sample", "0"]
-    c = subprocess.run([sys.executable, bench, "--gpus", "2", "--path", "c",
-                        "--replicas-on-one-gpu", "--queries", "150000"] +
-                       common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       timeout=600)
-    assert c.returncode == 0, c.stderr.decode()[-2000:]
-    a = json.loads(c.stdout.decode().strip().splitlines()[-1])
-    one = subprocess.run([sys.executable, bench, "--queries", "300000"] +
-                         common, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, timeout=600)
-    assert one.returncode == 0, one.stderr.decode()[-2000:]
-    b = json.loads(one.stdout.decode().strip().splitlines()[-1])
-    assert a["n_gpus"] == 2 and "host memory" in a["metric"]
-    assert a["matches"] == b["matches"] > 250000
-    assert a["candidates"] == b["candidates"]
+
+    def run(*args):
+        c = subprocess.run([sys.executable, bench] + list(args) + common,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=600)
+        assert c.returncode == 0, c.stderr.decode()[-2000:]
+        lines = [l for l in c.stdout.decode().splitlines() if l.strip()]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    a = run("--gpus", "2", "--replicas-on-one-gpu", "--queries", "150000")
+    h = run("--gpus", "2", "--path", "c", "--host", "--replicas-on-one-gpu",
+            "--queries", "150000")
+    b = run("--queries", "300000")
+    assert a["n_gpus"] == 2 and "resident in HBM" in a["config"]["path"]
+    assert "30 Mbp" in a["config"]["workload"]
+    assert h["n_gpus"] == 2 and "host memory" in h["metric"]
+    for x in (a, h):
+        assert x["matches"] == b["matches"] > 250000
+        assert x["candidates"] == b["candidates"]
+        assert x["query_suffix_searches"] == b["query_suffix_searches"]
 
 
 def test_queries_in_any_order_and_outside_the_buffer(V, MG):

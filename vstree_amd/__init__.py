@@ -65,6 +65,12 @@ class IndexInfo(C.Structure):
                 ("deepprefix", C.c_uint32)]
 
 
+class QueriesInfo(C.Structure):
+    _fields_ = [("numofqueries", C.c_uint64), ("numofsymbols", C.c_uint64),
+                ("minlength", C.c_uint64), ("maxlength", C.c_uint64),
+                ("offset", C.c_uint64), ("device", C.c_int)]
+
+
 class SinkParams(C.Structure):
     _fields_ = [("kind", C.c_int), ("palindromic", C.c_int),
                 ("selfpalindromic", C.c_int), ("showmode", C.c_uint32), ("numofchars", C.c_uint32),
@@ -135,6 +141,7 @@ def _load():
         "vsa_queries_reverse_complement": (I, [V, PP]),
         "vsa_queries_free": (None, [V]),
         "vsa_queries_set_offset": (I, [V, U64]),
+        "vsa_queries_getinfo": (I, [V, C.POINTER(QueriesInfo)]),
         "vsa_result_count": (U64, [V]),
         "vsa_result_getstats": (I, [V, C.POINTER(Stats)]),
         "vsa_result_fetch": (I, [V, V, U64]),
@@ -340,6 +347,11 @@ class Queries:
 
     def set_offset(self, offset):
         _check(lib.vsa_queries_set_offset(self._h, int(offset)))
+
+    def info(self):
+        qi = QueriesInfo()
+        _check(lib.vsa_queries_getinfo(self._h, C.byref(qi)))
+        return qi
 
     def reverse_complement(self):
         """vmatch -p: every sequence reversed and complemented on its own"""

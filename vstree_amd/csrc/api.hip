@@ -1051,6 +1051,23 @@ extern "C" int vsa_queries_set_offset(vsa_queries *q, uint64_t offset)
   return 0;
 }
 
+extern "C" int vsa_queries_getinfo(const vsa_queries *q,
+                                   vsa_queries_info *info)
+{
+  if (q == nullptr || info == nullptr)
+  {
+    VSA_ERROR("vsa_queries_getinfo: NULL argument");
+    return -1;
+  }
+  info->numofqueries = q->nq;
+  info->numofsymbols = q->nsymbols;
+  info->minlength = q->minlength;
+  info->maxlength = q->maxlength;
+  info->offset = q->seqoffset;
+  info->device = q->device;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // results
 // ---------------------------------------------------------------------------

@@ -11,9 +11,12 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -47,10 +50,111 @@ struct RankOut
   std::string message;
   std::vector<vsa_match> matches;
   vsa_stats stats;
-  // -mum: this rank's candidates grouped by receiving rank (device memory)
+  // -mum: this rank's candidates grouped by receiving rank (device memory;
+  // released with the object, whichever way the job ends)
   void *sendbuf = nullptr;
+  int sendbufdevice = 0;
   std::vector<uint64_t> counts, maxright;
   uint64_t ncand = 0;
+  RankOut() = default;
+  RankOut(const RankOut &) = delete;
+  RankOut &operator=(const RankOut &) = delete;
+  ~RankOut()
+  {
+    if (sendbuf != nullptr)
+    {
+      (void) vsa_device_free(sendbuf, sendbufdevice);
+    }
+  }
+};
+
+// The host threads of a replica set: replica r >= 1 has a thread of its own
+// for as long as the set lives, the caller's thread drives replica 0.  A job
+// is handed to all of them at once and joined (two condition variables; a
+// std::thread per replica and call cost more than the exchange they drive).
+struct Crew
+{
+  std::mutex lock;
+  std::condition_variable wake, done;
+  std::function<void(uint32_t)> job;
+  uint64_t generation = 0;
+  uint32_t pending = 0;
+  bool stop = false;
+  std::vector<std::thread> threads;
+
+  void start(uint32_t world)
+  {
+    for (uint32_t r = 1; r < world; r++)
+    {
+      threads.emplace_back([this, r] { loop(r); });
+    }
+  }
+  void loop(uint32_t r)
+  {
+    uint64_t seen = 0;
+    for (;;)
+    {
+      std::function<void(uint32_t)> f;
+      {
+        std::unique_lock<std::mutex> g(lock);
+        wake.wait(g, [&] { return stop || generation != seen; });
+        if (stop)
+        {
+          return;
+        }
+        seen = generation;
+        f = job;
+      }
+      f(r);
+      {
+        std::lock_guard<std::mutex> g(lock);
+        pending--;
+      }
+      done.notify_all();
+    }
+  }
+  template <typename F> void run(F f)
+  {
+    if (threads.empty())
+    {
+      f(0u);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> g(lock);
+      job = f;
+      generation++;
+      pending = (uint32_t) threads.size();
+    }
+    wake.notify_all();
+    f(0u);
+    std::unique_lock<std::mutex> g(lock);
+    done.wait(g, [&] { return pending == 0; });
+  }
+  void finish()
+  {
+    {
+      std::lock_guard<std::mutex> g(lock);
+      stop = true;
+    }
+    wake.notify_all();
+    for (std::thread &t : threads)
+    {
+      t.join();
+    }
+    threads.clear();
+  }
+};
+
+// what a replica keeps from call to call for the device-resident -mum form:
+// its candidate rows grouped by receiving replica, the rows it receives, the
+// split sizes / right ends (2 * world words) on the device and page-locked
+struct Exchange
+{
+  void *rows = nullptr, *recv = nullptr;
+  uint64_t rowcap = 0, recvcap = 0;
+  uint64_t *devmeta = nullptr, *hostmeta = nullptr;
+  hipStream_t copy = nullptr;
 };
 
 } // namespace
@@ -63,6 +167,8 @@ struct vsa_multi
   std::vector<hipStream_t> streams;
   std::vector<unsigned long long *> counters; // device, 4 words per replica
   int usedrccl = 0;
+  Crew crew;
+  std::vector<Exchange> xch;
 };
 
 namespace
@@ -105,7 +211,8 @@ void initcomms(vsa_multi *m)
 
 // sums 4 counters per replica over all replicas: RCCL when there are
 // communicators, the host otherwise.  Every replica ends with the totals.
-int reducecounters(vsa_multi *m, std::vector<RankOut> &out, vsa_stats *total)
+int reducecounters(vsa_multi *m, const std::vector<vsa_stats> &st,
+                   vsa_stats *total)
 {
   const size_t world = m->dev.size();
   unsigned long long sum[4] = {0, 0, 0, 0};
@@ -116,8 +223,8 @@ int reducecounters(vsa_multi *m, std::vector<RankOut> &out, vsa_stats *total)
     for (size_t r = 0; r < world && ok; r++)
     {
       const unsigned long long mine[4] = {
-          out[r].stats.count, out[r].stats.sumlength, out[r].stats.searches,
-          out[r].stats.candidates};
+          st[r].count, st[r].sumlength, st[r].searches,
+          st[r].candidates};
       ok = hipSetDevice(m->dev[r]) == hipSuccess &&
            hipMemcpyAsync(m->counters[r], mine, sizeof mine,
                           hipMemcpyHostToDevice, m->streams[r]) == hipSuccess &&
@@ -154,10 +261,10 @@ int reducecounters(vsa_multi *m, std::vector<RankOut> &out, vsa_stats *total)
   {
     for (size_t r = 0; r < world; r++)
     {
-      sum[0] += out[r].stats.count;
-      sum[1] += out[r].stats.sumlength;
-      sum[2] += out[r].stats.searches;
-      sum[3] += out[r].stats.candidates;
+      sum[0] += st[r].count;
+      sum[1] += st[r].sumlength;
+      sum[2] += st[r].searches;
+      sum[3] += st[r].candidates;
     }
   }
   if (total != nullptr)
@@ -170,10 +277,12 @@ int reducecounters(vsa_multi *m, std::vector<RankOut> &out, vsa_stats *total)
     for (size_t r = 0; r < world; r++)
     {
       total->search_kernel_ms =
-          std::max(total->search_kernel_ms, out[r].stats.search_kernel_ms);
+          std::max(total->search_kernel_ms, st[r].search_kernel_ms);
       total->total_device_ms =
-          std::max(total->total_device_ms, out[r].stats.total_device_ms);
-      total->kernel_searches += out[r].stats.kernel_searches;
+          std::max(total->total_device_ms, st[r].total_device_ms);
+      total->kernel_searches += st[r].kernel_searches;
+      total->first_kernel_ms =
+          std::max(total->first_kernel_ms, st[r].first_kernel_ms);
     }
   }
   return 0;
@@ -305,6 +414,7 @@ void searchblock(const Job &job, uint32_t r, RankOut &o)
       o.counts.assign(world, 0);
       o.maxright.assign(world, 0);
       const uint64_t rowbytes = job.lengthbits != 0 ? 16 : sizeof(vsa_match);
+      o.sendbufdevice = m->dev[r];
       if (vsa_device_malloc(std::max<uint64_t>(o.ncand, 1) * rowbytes,
                             m->dev[r], &o.sendbuf) != 0 ||
           vsa_result_partition(res, world, job.totallength, o.sendbuf,
@@ -397,6 +507,7 @@ void filterrange(const Job &job, uint32_t r, std::vector<RankOut> &all,
   (void) vsa_device_free(recv, m->dev[r]);
 }
 
+// before the set has its crew (construction): a thread per replica
 template <typename F> void onallreplicas(uint32_t world, F f)
 {
   std::vector<std::thread> threads;
@@ -409,6 +520,14 @@ template <typename F> void onallreplicas(uint32_t world, F f)
   {
     t.join();
   }
+}
+
+// the set is complete: communicators, host threads, exchange state
+void commission(vsa_multi *m)
+{
+  initcomms(m);
+  m->xch.resize(m->dev.size());
+  m->crew.start((uint32_t) m->dev.size());
 }
 
 } // namespace
@@ -446,7 +565,7 @@ extern "C" int vsa_multi_from_tables(const vsa_tables *tables,
       return rc;
     }
   }
-  initcomms(m);
+  commission(m);
   *multi = m;
   return 0;
 }
@@ -493,7 +612,7 @@ extern "C" int vsa_multi_replicate(vsa_index *first, const int *devices,
       return rc;
     }
   }
-  initcomms(m);
+  commission(m);
   *multi = m;
   return 0;
 }
@@ -518,6 +637,32 @@ extern "C" void vsa_multi_close(vsa_multi *m)
   if (m == nullptr)
   {
     return;
+  }
+  m->crew.finish();
+  for (size_t r = 0; r < m->xch.size(); r++)
+  {
+    Exchange &x = m->xch[r];
+    (void) hipSetDevice(m->dev[r]);
+    if (x.rows != nullptr)
+    {
+      (void) vsa_device_free(x.rows, m->dev[r]);
+    }
+    if (x.recv != nullptr)
+    {
+      (void) vsa_device_free(x.recv, m->dev[r]);
+    }
+    if (x.devmeta != nullptr)
+    {
+      (void) vsa_device_free(x.devmeta, m->dev[r]);
+    }
+    if (x.hostmeta != nullptr)
+    {
+      (void) hipHostFree(x.hostmeta);
+    }
+    if (x.copy != nullptr)
+    {
+      (void) hipStreamDestroy(x.copy);
+    }
   }
   for (size_t r = 0; r < m->comms.size(); r++)
   {
@@ -611,7 +756,7 @@ int multi_findmatches(vsa_multi *m, int mode, uint64_t searchlength,
     job.lengthbits = (longest < 0xFFFFu && (nq >> 47) == 0) ? bits : 0;
   }
   std::vector<RankOut> out(world), filtered(world);
-  onallreplicas(world, [&](uint32_t r) { searchblock(job, r, out[r]); });
+  m->crew.run([&](uint32_t r) { searchblock(job, r, out[r]); });
   int rc = 0;
   uint32_t failed = world;
   for (uint32_t r = 0; r < world; r++)
@@ -637,7 +782,7 @@ int multi_findmatches(vsa_multi *m, int mode, uint64_t searchlength,
   std::vector<RankOut> *lists = &out;
   if (mode == VSA_MULTI_MUM && rc == 0)
   {
-    onallreplicas(world, [&](uint32_t r) {
+    m->crew.run([&](uint32_t r) {
       filtered[r].stats = out[r].stats;
       filterrange(job, r, out, filtered[r]);
     });
@@ -654,16 +799,7 @@ int multi_findmatches(vsa_multi *m, int mode, uint64_t searchlength,
     }
     lists = &filtered;
   }
-  if (mode == VSA_MULTI_MUM)
-  {
-    for (uint32_t r = 0; r < world; r++)
-    {
-      if (out[r].sendbuf != nullptr)
-      {
-        (void) vsa_device_free(out[r].sendbuf, m->dev[r]);
-      }
-    }
-  }
+  // (the send buffers of a -mum job go with `out`, whichever way this ends)
   // the reference stops at the first error: lists of the replicas before the
   // failing one, then what that one had delivered
   uint64_t totalcount = 0;
@@ -695,7 +831,12 @@ int multi_findmatches(vsa_multi *m, int mode, uint64_t searchlength,
   *count = totalcount;
   if (rc == 0)
   {
-    rc = reducecounters(m, *lists, total);
+    std::vector<vsa_stats> st(world);
+    for (uint32_t r = 0; r < world; r++)
+    {
+      st[r] = (*lists)[r].stats;
+    }
+    rc = reducecounters(m, st, total);
   }
   return rc;
 }
@@ -786,4 +927,356 @@ extern "C" int vsa_multi_findmatches_cb(vsa_multi *m, int mode,
   }
   vsa_multi_free_matches(matches);
   return rc;
+}
+
+// ---- the device-resident form ------------------------------------------------
+// Every replica's block of queries lies in its HBM already and the lists stay
+// there: nothing of a job crosses PCIe but 2 * world numbers per replica
+// (-mum: the split sizes of the exchange) and the four counters.
+
+namespace
+{
+
+struct DeviceJob
+{
+  vsa_multi *m;
+  int mode;
+  uint64_t searchlength, totallength;
+  uint32_t lengthbits;
+  vsa_queries *const *blocks;
+  vsa_result **results;
+};
+
+struct DeviceOut
+{
+  int rc = 0;
+  std::string message;
+  vsa_stats stats;
+  uint64_t ncand = 0;
+};
+
+int fail(DeviceOut &o, int rc, const char *what)
+{
+  o.rc = rc;
+  o.message = what != nullptr ? what : vsa_messagespace();
+  return rc;
+}
+
+// room for `rows` rows of 16 bytes in *buf (kept from call to call)
+int growrows(void **buf, uint64_t *cap, uint64_t rows, int device)
+{
+  if (rows <= *cap && *buf != nullptr)
+  {
+    return 0;
+  }
+  if (*buf != nullptr)
+  {
+    (void) vsa_device_free(*buf, device);
+    *buf = nullptr;
+    *cap = 0;
+  }
+  const uint64_t want = rows + rows / 8 + 4096;
+  if (vsa_device_malloc(want * 16, device, buf) != 0)
+  {
+    return -100;
+  }
+  *cap = want;
+  return 0;
+}
+
+// phase 1 of replica r: the search on its block; -mum: the candidates grouped
+// by the replica that filters their range of the index (the rows for r itself
+// behind all others: they do not travel), split sizes and right ends fetched
+void devicesearch(const DeviceJob &job, uint32_t r, DeviceOut &o)
+{
+  vsa_multi *m = job.m;
+  const uint32_t world = (uint32_t) m->dev.size();
+  memset(&o.stats, 0, sizeof o.stats);
+  job.results[r] = nullptr;
+  if (hipSetDevice(m->dev[r]) != hipSuccess)
+  {
+    (void) fail(o, -100, "hipSetDevice failed");
+    return;
+  }
+  vsa_result *res = nullptr;
+  int rc = 0;
+  switch (job.mode)
+  {
+    case VSA_MULTI_COMPLETE:
+      rc = vsa_findcompletematches(m->ix[r], job.blocks[r], &res);
+      break;
+    case VSA_MULTI_MEM:
+      rc = vsa_findquerymatches(m->ix[r], job.blocks[r], 0, 0,
+                                job.searchlength, &res);
+      break;
+    case VSA_MULTI_MUMCAND:
+      rc = vsa_findquerymatches(m->ix[r], job.blocks[r], 1, 1,
+                                job.searchlength, &res);
+      break;
+    default:
+    {
+      Exchange &x = m->xch[r];
+      if (x.devmeta == nullptr &&
+          (vsa_device_malloc(2 * (uint64_t) world * 8, m->dev[r],
+                             (void **) &x.devmeta) != 0 ||
+           hipHostMalloc((void **) &x.hostmeta, 2 * (size_t) world * 8,
+                         hipHostMallocDefault) != hipSuccess ||
+           hipStreamCreateWithFlags(&x.copy, hipStreamNonBlocking) !=
+               hipSuccess))
+      {
+        (void) fail(o, -100, "vsa_multi: no memory for the exchange state");
+        return;
+      }
+      if (growrows(&x.rows, &x.rowcap, 1, m->dev[r]) != 0)
+      {
+        (void) fail(o, -100, nullptr);
+        return;
+      }
+      rc = vsa_findmumcandidates_grouped(m->ix[r], job.blocks[r],
+                                         job.searchlength, job.lengthbits,
+                                         world, (int) r, x.rows, x.rowcap,
+                                         x.devmeta, &res);
+      if (rc == 1)
+      {
+        // more candidates than the row buffer holds: make room, group
+        rc = growrows(&x.rows, &x.rowcap, vsa_result_count(res), m->dev[r]);
+        if (rc == 0)
+        {
+          rc = vsa_result_partition_device(res, world, (int) r,
+                                           job.totallength, x.rows, x.devmeta);
+        }
+      }
+      if (rc == 0)
+      {
+        // (the grouping is queued on the device's default stream: the copy
+        // behind it on the same stream sees its numbers, and the rows are in
+        // place when it has arrived)
+        if (hipMemcpyAsync(x.hostmeta, x.devmeta, 2 * (size_t) world * 8,
+                           hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+            hipStreamSynchronize(nullptr) != hipSuccess)
+        {
+          rc = fail(o, -100, "vsa_multi: split sizes did not arrive");
+        }
+      }
+      if (res != nullptr)
+      {
+        (void) vsa_result_getstats(res, &o.stats);
+        o.ncand = vsa_result_count(res);
+        vsa_result_free(res); // the rows hold what the filter needs
+        res = nullptr;
+      }
+      if (rc != 0 && o.rc == 0)
+      {
+        (void) fail(o, rc, nullptr);
+      }
+      return;
+    }
+  }
+  if (rc != 0)
+  {
+    (void) fail(o, rc, nullptr); // -complete: the matches so far still count
+  }
+  if (res != nullptr)
+  {
+    (void) vsa_result_getstats(res, &o.stats);
+  }
+  job.results[r] = res;
+}
+
+// phase 2 of replica r (-mum): range r of every other replica comes over by
+// peer copies (one xGMI hop each); the filter reads r's own rows where they
+// lie and the received ones as one list
+void devicefilter(const DeviceJob &job, uint32_t r,
+                  const std::vector<DeviceOut> &found, DeviceOut &o)
+{
+  vsa_multi *m = job.m;
+  const uint32_t world = (uint32_t) m->dev.size();
+  Exchange &x = m->xch[r];
+  if (hipSetDevice(m->dev[r]) != hipSuccess)
+  {
+    (void) fail(o, -100, "hipSetDevice failed");
+    return;
+  }
+  uint64_t nrecv = 0, carry = 0;
+  for (uint32_t s = 0; s < world; s++)
+  {
+    const uint64_t *meta = m->xch[s].hostmeta;
+    if (s != r)
+    {
+      nrecv += meta[r];
+    }
+    for (uint32_t p = 0; p < r; p++)
+    {
+      carry = std::max(carry, meta[world + p]);
+    }
+  }
+  if (growrows(&x.recv, &x.recvcap, nrecv, m->dev[r]) != 0)
+  {
+    (void) fail(o, -100, nullptr);
+    return;
+  }
+  uint64_t at = 0;
+  bool ok = true;
+  for (uint32_t s = 0; s < world && ok; s++)
+  {
+    if (s == r)
+    {
+      continue;
+    }
+    const uint64_t *meta = m->xch[s].hostmeta;
+    uint64_t before = 0; // rows of replica s in front of its part r
+    for (uint32_t p = 0; p < r; p++)
+    {
+      before += (p == s) ? 0 : meta[p];
+    }
+    const uint64_t c = meta[r];
+    if (c > 0)
+    {
+      ok = hipMemcpyPeerAsync((char *) x.recv + at * 16, m->dev[r],
+                              (const char *) m->xch[s].rows + before * 16,
+                              m->dev[s], c * 16, x.copy) == hipSuccess;
+      at += c;
+    }
+  }
+  ok = ok && hipStreamSynchronize(x.copy) == hipSuccess;
+  if (!ok)
+  {
+    (void) fail(o, -100, "vsa_multi: peer copy of MUM candidates failed");
+    return;
+  }
+  const uint64_t own = x.hostmeta[r];
+  vsa_result *res = nullptr;
+  const int rc = vsa_mumuniqueinquery_range_packed2(
+      (const char *) x.rows + (found[r].ncand - own) * 16, own, x.recv, nrecv,
+      job.lengthbits, job.totallength, m->dev[r], carry, &res);
+  if (rc != 0)
+  {
+    (void) fail(o, rc, nullptr);
+    return;
+  }
+  vsa_stats fs;
+  (void) vsa_result_getstats(res, &fs);
+  o.stats = found[r].stats;
+  o.stats.count = fs.count;
+  o.stats.sumlength = fs.sumlength;
+  o.stats.candidates = found[r].ncand;
+  o.stats.total_device_ms += fs.total_device_ms;
+  job.results[r] = res;
+}
+
+} // namespace
+
+extern "C" int vsa_multi_findmatches_device(vsa_multi *m, int mode,
+                                            uint64_t searchlength,
+                                            vsa_queries *const *blocks,
+                                            vsa_result **results,
+                                            vsa_stats *total)
+{
+  if (m == nullptr || blocks == nullptr || results == nullptr || mode < 0 ||
+      mode > VSA_MULTI_MUM)
+  {
+    seterror("vsa_multi_findmatches_device: bad argument");
+    return -1;
+  }
+  const uint32_t world = (uint32_t) m->dev.size();
+  vsa_index_info info;
+  if (vsa_index_getinfo(m->ix[0], &info) != 0)
+  {
+    return -1;
+  }
+  uint64_t longest = 1, lastquery = 0;
+  for (uint32_t r = 0; r < world; r++)
+  {
+    vsa_queries_info qi;
+    results[r] = nullptr;
+    if (blocks[r] == nullptr || vsa_queries_getinfo(blocks[r], &qi) != 0 ||
+        qi.device != m->dev[r])
+    {
+      char msg[160];
+      snprintf(msg, sizeof msg,
+               "vsa_multi_findmatches_device: block %u is not a batch of "
+               "queries on device %d", r, m->dev[r]);
+      seterror(msg);
+      return -1;
+    }
+    longest = std::max(longest, qi.maxlength);
+    lastquery = std::max(lastquery, qi.offset + qi.numofqueries);
+  }
+  DeviceJob job;
+  job.m = m;
+  job.mode = mode;
+  job.searchlength = searchlength;
+  job.totallength = info.totallength;
+  job.blocks = blocks;
+  job.results = results;
+  job.lengthbits = 0;
+  if (mode == VSA_MULTI_MUM)
+  {
+    // the pairs of all replicas are laid out alike: the length bits of the
+    // longest query of the job
+    uint32_t bits = 0;
+    while ((longest >> bits) != 0)
+    {
+      bits++;
+    }
+    if (longest >= 0xFFFFu || (lastquery >> 47) != 0)
+    {
+      seterror("vsa_multi_findmatches_device: -mum takes queries of fewer "
+               "than 65 535 symbols and query numbers below 2^47 (the pair "
+               "form of the candidates); vsa_multi_findmatches has no such "
+               "limit");
+      return -2;
+    }
+    job.lengthbits = bits;
+  }
+  std::vector<DeviceOut> found(world), filtered(world);
+  m->crew.run([&](uint32_t r) { devicesearch(job, r, found[r]); });
+  int rc = 0;
+  uint32_t failed = world;
+  for (uint32_t r = 0; r < world && rc == 0; r++)
+  {
+    if (found[r].rc != 0)
+    {
+      rc = found[r].rc;
+      failed = r;
+      seterror(found[r].message);
+    }
+  }
+  std::vector<DeviceOut> *outs = &found;
+  if (mode == VSA_MULTI_MUM && rc == 0)
+  {
+    m->crew.run(
+        [&](uint32_t r) { devicefilter(job, r, found, filtered[r]); });
+    for (uint32_t r = 0; r < world && rc == 0; r++)
+    {
+      if (filtered[r].rc != 0)
+      {
+        rc = filtered[r].rc;
+        failed = r;
+        seterror(filtered[r].message);
+      }
+    }
+    outs = &filtered;
+  }
+  if (rc != 0)
+  {
+    // the reference stops at the first error: the lists of the replicas in
+    // front of the failing one and what that one had found stay (-complete,
+    // -l, -mum cand); a -mum job that failed has no list
+    for (uint32_t r = 0; r < world; r++)
+    {
+      if (results[r] != nullptr && (mode == VSA_MULTI_MUM || r > failed))
+      {
+        vsa_result_free(results[r]);
+        results[r] = nullptr;
+      }
+    }
+    return rc;
+  }
+  std::vector<vsa_stats> st(world);
+  for (uint32_t r = 0; r < world; r++)
+  {
+    st[r] = (*outs)[r].stats;
+  }
+  return reducecounters(m, st, total);
 }

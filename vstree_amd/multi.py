@@ -25,6 +25,8 @@ SIGNATURES = {
     "vsa_multi_findmatches": (_I, [_V, _I, _U64, _V, _U64, _V, _V, _U64, _PP,
                                    C.POINTER(_U64), C.POINTER(V.Stats)]),
     "vsa_multi_free_matches": (None, [_V]),
+    "vsa_multi_findmatches_device": (_I, [_V, _I, _U64, _PP, _PP,
+                                          C.POINTER(V.Stats)]),
     "vsa_multi_findmatches_cb": (_I, [_V, _I, _U64, _V, _U64, _V, _V, _U64,
                                       V.PROCESSMATCH, _V]),
     "vsa_multi_findapproxcompletematches": (
@@ -110,6 +112,22 @@ class Multi:
             C.memmove(m.ctypes.data, out.value, n.value * 32)
         lib.vsa_multi_free_matches(out)
         return m, st, rc, V.messagespace() if rc != 0 else ""
+
+    def findmatches_device(self, mode, blocks, searchlength=0):
+        """blocks[r]: a V.Queries on the device of replica r (offset set) ->
+        ([V.Result per replica], Stats of the job, rc, message); the lists
+        stay in HBM"""
+        n = self.ndevices()
+        assert len(blocks) == n
+        qs = (C.c_void_p * n)(*[b._h for b in blocks])
+        rs = (C.c_void_p * n)()
+        st = V.Stats()
+        rc = lib.vsa_multi_findmatches_device(
+            self._h, int(mode), int(searchlength), qs, rs, C.byref(st))
+        msg = V.messagespace() if rc != 0 else ""
+        res = [V.Result(C.c_void_p(rs[r])) if rs[r] else None
+               for r in range(n)]
+        return res, st, rc, msg
 
     def findapproxcompletematches(self, symbols, start, length, doedist,
                                   distvalue, percent=False):
