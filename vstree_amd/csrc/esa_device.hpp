@@ -34,9 +34,6 @@
 #include "vsa_internal.hpp"
 #include <type_traits>
 
-// VSA_TUNE bit 20 (round 3, see esa_search.hip)
-#define VSA_TUNE_OLDBUCKET (1u << 20) // small buckets by three loads from esa8
-
 #define VSA_ISSPECIAL(c) ((c) >= (uint8_t) VSA_WILDCARD) // chardef.h:37
 
 __device__ __forceinline__ uint64_t vsa_load8(const uint8_t *p)
@@ -809,19 +806,16 @@ enum
 {
   VSA_LOC_NONE = 0, // nothing in the index shares D symbols with the query
   VSA_LOC_FOUND = 1,
-  VSA_LOC_SLOW = 2, // take the reference walk (special symbols, ties, ...)
-  // (DEFER only) located, but the matched length needs the comparison on the
-  // text: maxlcp = the symbols known to match, w / hit as for FOUND
-  VSA_LOC_DEFER = 3
+  VSA_LOC_SLOW = 2  // take the reference walk (special symbols, ties, ...)
 };
 
 // Deep locate.  Must be called by all lanes of the wavefront (inactive lanes
 // pass active = false): the key search runs a wavefront-uniform number of
 // rounds.  On VSA_LOC_FOUND: maxlcp = the maximal matched length over the
 // whole index, w = a suffix-array index attaining it.
-__device__ __forceinline__ uint64_t vsa_ld_entry(const uint64_t *p, bool nt)
+__device__ __forceinline__ uint64_t vsa_ld_entry(const uint64_t *p)
 {
-  return nt ? __builtin_nontemporal_load(p) : *p;
+  return *p;
 }
 
 // what the deep locate knows about the located suffix w without further
@@ -836,17 +830,15 @@ struct DeepHit
 };
 
 // What the first round trip of the deep locate brings: the bounds of the deep
-// bucket of the query's first D symbols with the bucket's first entries, and
-// the query's key symbols.  Two-phase callers (k_query_search_planned2) look
-// at it, finish most searches on the spot and pass the others on.
+// bucket of the query's first D symbols with the bucket's first entry, and
+// the query's key symbols.
 struct DeepFront
 {
-  uint64_t raw;                  // word 0 of the slot as loaded
-  uint64_t left;                 // first suffix of the bucket
-  uint64_t first, second, third; // esa8[left..] from the fused table (or 0)
-  uint32_t cnt, qkey, limit;     // suffixes in the bucket; key symbols, how
-                                 // many of them the query has
-  int state;                     // VSA_LOC_NONE / FOUND (= go on) / SLOW
+  uint64_t left;             // first suffix of the bucket
+  uint64_t first;            // esa8[left] from the slot (0: empty bucket)
+  uint32_t cnt, qkey, limit; // suffixes in the bucket; key symbols, how
+                             // many of them the query has
+  int state;                 // VSA_LOC_NONE / FOUND (= go on) / SLOW
 };
 
 template <bool PQ = false, typename IDX = uint32_t, typename QT = PackedQuery>
@@ -855,12 +847,11 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
                uint32_t querylen, DeepFront &f,
                const QT *pq = nullptr, uint32_t pqoff = 0)
 {
-  const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   f.state = VSA_LOC_NONE;
-  f.raw = f.left = 0;
+  f.left = 0;
   f.cnt = f.qkey = f.limit = 0;
-  f.first = f.second = f.third = 0;
+  f.first = 0;
   if (active)
   {
     uint32_t valid = 32; // leading regular symbols inside the query
@@ -917,29 +908,11 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
       {
         f.limit = VSA_KEYSYMS;
       }
-      // (left, mid) of the deep bucket -- with the first entry of the
-      // bucket if the fused table is there: one load
-      uint64_t b;
-      if (ix.slot16 != nullptr)
-      {
-        const uint64_t *sp = ix.slot16 + (uint64_t) ix.slotwords * code;
-        const vsa_u128 sl = vsa_load16(sp);
-        b = sl.lo;
-        f.first = sl.hi;
-        if (ix.slotwords == 4)
-        {
-          // the other half of the 32-byte slot: same 64-byte sector
-          const vsa_u128 sm = vsa_load16(sp + 2);
-          f.second = sm.lo;
-          f.third = sm.hi;
-        }
-      } else
-      {
-        b = vsa_ld_entry(reinterpret_cast<const uint64_t *>(ix.bck2) + code,
-                         nt);
-      }
-      f.raw = b;
-      vsa_slotbounds<IDX>(b, f.left, f.cnt);
+      // (left, mid) of the deep bucket with the bucket's first entry: one
+      // 16-byte load (deep tables always come with the fused slot table)
+      const vsa_u128 sl = vsa_load16(ix.slot16 + 2 * code);
+      f.first = sl.hi;
+      vsa_slotbounds<IDX>(sl.lo, f.left, f.cnt);
       f.state = (f.cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
     }
   }
@@ -981,8 +954,8 @@ vsa_extend_tie(const DevIndex<IDX> &ix, uint64_t sstart, const uint8_t *query,
 }
 
 // the deep locate from a front that is at hand (all lanes, see below)
-template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
-          typename IDX = uint32_t, typename QT = PackedQuery>
+template <int AHEAD = 1, bool PQ = false, typename IDX = uint32_t,
+          typename QT = PackedQuery>
 __device__ __forceinline__ int
 vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
                      const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
@@ -1005,7 +978,6 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
   // maxlcp is then only a lower bound.
   // AHEAD: see vsa_compare32.  needleft: hit.leftsym is wanted for matches
   // of at least this length (the MUM test).
-  const bool nt = (ix.tune & 1u) != 0;
   const uint32_t D = ix.D;
   int state = f.state;
   // first suffix of the deep bucket: a register pair only for wide tables
@@ -1013,7 +985,7 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
       dl = (typename std::conditional<sizeof(IDX) == 4, uint32_t,
                                       uint64_t>::type) f.left;
   const uint32_t cnt = f.cnt, qkey = f.qkey, limit = f.limit;
-  const uint64_t first = f.first, second = f.second, third = f.third;
+  const uint64_t first = f.first;
 
   const bool searching = state == VSA_LOC_FOUND;
   // only the first `limit` key symbols of the query exist
@@ -1025,17 +997,13 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
   const bool small = searching && cnt <= 4;
   const uint32_t ksh = 2 * (VSA_KEYSYMS - limit);
   uint64_t e[5] = {0, 0, 0, 0, 0};
-  if (small && ix.slot16 != nullptr &&
-      (cnt == 1 || (cnt <= 3 && ix.slotwords == 4)))
+  if (small && cnt == 1)
   {
     // the whole bucket came with the bounds.  The entry behind it belongs to
     // another bucket and shares fewer than D symbols with it, so its lcp byte
-    // (0 here: the table holds 0 for entries the bucket does not have) is
-    // below every match length either way: nothing else is needed.
+    // (0 here) is below every match length either way: nothing else is needed.
     e[0] = first;
-    e[1] = second;
-    e[2] = third;
-  } else if (small && ix.slot16 != nullptr && (ix.tune & VSA_TUNE_OLDBUCKET) == 0)
+  } else if (small)
   {
     // the first entry came with the bounds: entries 1, 2 in one load, and 3, 4
     // in a second one for the buckets that have them (a divergent load costs
@@ -1053,15 +1021,6 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
       e[3] = e34.lo;
       e[4] = e34.hi;
     }
-  } else if (small)
-  {
-    const uint64_t *p = ix.esa8 + (uint64_t) dl;
-    const vsa_u128 e01 = vsa_load16(p), e23 = vsa_load16(p + 2);
-    e[0] = e01.lo;
-    e[1] = e01.hi;
-    e[2] = e23.lo;
-    e[3] = e23.hi;
-    e[4] = vsa_ld_entry(p + 4, nt);
   }
   // lower bound on keys: lo = number of bucket entries whose key is smaller
   // than the query's
@@ -1112,7 +1071,7 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
     if (lo < hi)
     {
       const uint32_t mid = (lo + hi) >> 1;
-      const uint64_t em = vsa_ld_entry(ix.esa8 + (uint64_t) dl + mid, nt);
+      const uint64_t em = vsa_ld_entry(ix.esa8 + (uint64_t) dl + mid);
       flagged = flagged || (em & VSA_KEYFLAG) != 0;
       const uint32_t tk =
           ((uint32_t) (em >> VSA_KEYSHIFT) & VSA_KEYMASK) >> ksh;
@@ -1149,15 +1108,15 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
       const uint64_t base = (uint64_t) dl + lo;
       if (base > 0)
       {
-        epred = vsa_ld_entry(ix.esa8 + base - 1, nt);
+        epred = vsa_ld_entry(ix.esa8 + base - 1);
       }
       if (base <= ix.n)
       {
-        esucc = vsa_ld_entry(ix.esa8 + base, nt);
+        esucc = vsa_ld_entry(ix.esa8 + base);
       }
       if (base + 1 <= ix.n)
       {
-        enext = vsa_ld_entry(ix.esa8 + base + 1, nt);
+        enext = vsa_ld_entry(ix.esa8 + base + 1);
       }
     }
     flagged = flagged || (haspred && (epred & VSA_KEYFLAG) != 0) ||
@@ -1225,14 +1184,7 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
       extend = false;
     }
   }
-  // one text comparison for the lanes with a tie, all at the same time --
-  // or, DEFER, none here: the few lanes with a tie (true matches, usually
-  // long) leave for a kernel of their own instead of holding up the
-  // wavefront, whose other lanes are done
-  if (DEFER)
-  {
-    return (state == VSA_LOC_FOUND && extend) ? VSA_LOC_DEFER : state;
-  }
+  // one text comparison for the lanes with a tie, all at the same time
   if (extend)
   {
     vsa_extend_tie<AHEAD, PQ>(ix, vsa_entrystart(ix, esucc, (uint64_t) dl + lo),
@@ -1241,8 +1193,8 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
   return state;
 }
 
-template <int AHEAD = 1, bool DEFER = false, bool PQ = false,
-          typename IDX = uint32_t, typename QT = PackedQuery>
+template <int AHEAD = 1, bool PQ = false, typename IDX = uint32_t,
+          typename QT = PackedQuery>
 __device__ __forceinline__ int
 vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
                 const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
@@ -1252,9 +1204,8 @@ vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
 {
   DeepFront f;
   vsa_deep_front<PQ>(ix, active, query, querylen, f, pq, pqoff);
-  return vsa_locate_deep_from<AHEAD, DEFER, PQ>(ix, f, query, querylen, maxlcp,
-                                                w, hit, needleft, qleft, pq,
-                                                pqoff);
+  return vsa_locate_deep_from<AHEAD, PQ>(ix, f, query, querylen, maxlcp, w,
+                                         hit, needleft, qleft, pq, pqoff);
 }
 
 // 64-lane helpers ----------------------------------------------------------

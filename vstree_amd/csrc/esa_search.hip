@@ -28,17 +28,17 @@
 //
 // rocPRIM supplies radix sort / scan / reduce only.
 //
-// Experiment switches (environment, read when an index is created):
-//   VSA_TUNE bit 0  nontemporal probes in the deep locate
-//            bit 1  no MUM work reduction at all (every offset is searched)
-//            bit 2  no work plan (anchor pass only)
-//            bit 3  anchor pass + plan instead of first pass + plan
-//            bit 4  MUM candidates as 32-byte records through the filter
-//                   (instead of pairs)
-//            bit 5  8-byte values in the pairs (instead of 4-byte ones)
-//            bits 8..19  workgroup size of K2 (64, 128, 256, 512)
-//            bit 20  small deep buckets by three loads from esa8 (round 2)
-//   VSA_NO_ESA8=1, VSA_DEEP_PREFIX=D   the keyed search array off / its depth
+// Switches (environment, read when an index is created):
+//   VSA_TUNE=2        no MUM work reduction: every offset of every read is
+//                     searched by the list form of the search kernel (the
+//                     cross-check of first pass + work plan)
+//   VSA_NO_ESA8=1     no deep tables: the reference walk, probe for probe
+//   VSA_DEEP_PREFIX=D their depth (default ceil(log4 n), at most 16)
+//   VSA_FORCE_WIDE=1  64-bit device tables whatever the size of the text
+// What was measured and dropped (32-byte slots, the two-phase and the deferring
+// search kernel, the anchor pass, the list form of planned batches, the filter
+// on rocPRIM scans, ...) is described in DESIGN.md section 4 with its numbers
+// under profiles/; the code left with round 4.
 #include <cstring>
 #include <algorithm>
 #include "esa_device.hpp"
@@ -430,7 +430,7 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   {
     const bool staged = ix.esa8 != nullptr && qs.dense != 0 &&
                         qs.uniformlen <= 128 && (qs.uniformlen & 3u) == 0 &&
-                        qs.uniformlen >= ix.D && (index->tune & 128u) == 0;
+                        qs.uniformlen >= ix.D;
     if (staged)
     {
       k_complete_search<IDX, true, true>
@@ -1014,12 +1014,10 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     return 0;
   }
   const uint32_t nshards = VSA_CURSOR_SHARDS;
-  const int qblock = (int) ((index->tune >> 8) & 0xFFF); // experiment switch
   const bool deepok = ix.esa8 != nullptr && searchlength >= ix.D;
   tall.start();
-  // MUM modes over batches of equal-length queries: anchor pass + work list
-  DevBuf wcount, wbase, wlq, wloff, wtemp, wplan, wlist, wfirste,
-      wfmlen, wfmdb, wboffset;
+  // MUM modes: first pass + work plan (mum_workplan.inc)
+  DevBuf wcount, wtemp, wplan, wlist, wfirste, wfmlen, wfmdb, wboffset;
   uint64_t nfirstpass = 0; // candidates of the first pass (k_append_first)
   uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
   // -mum with the filter: candidates as (sort key, value) pairs, see
@@ -1029,7 +1027,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
                          keeppairs ? forcebits : bitsfor(queries->maxlength),
                      dbbits = bitsfor(index->n);
   const bool packed = domum && (!domumcand || keeppairs) &&
-                      ((index->tune & 16u) == 0 || keeppairs) &&
                       lenbits + dbbits <= 64 &&
                       lenbits >= bitsfor(queries->maxlength) &&
                       queries->maxlength < 0xFFFFu &&
@@ -1045,17 +1042,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // 4-byte values where query number and offset fit (not for pairs that
   // travel to other ranks: those carry the global query number)
   const uint32_t valbits =
-      (packed && !keeppairs && (index->tune & 32u) == 0 &&
-       ((queries->nq << lenbits) >> 32) == 0)
+      (packed && !keeppairs && ((queries->nq << lenbits) >> 32) == 0)
           ? lenbits
           : 0;
   const size_t recsize = valbits != 0 ? 4 : (packed ? 8 : sizeof(vsa_match));
-  bool firstpass = false, fromplan = false, planemit = false;
+  bool fromplan = false, planemit = false;
   DevBuf pcursor, pdoff, psummary, prawout, prawkeys; // see PlanEmit
   uint64_t pcap = 0, nplan = 0;
-  const uint32_t *dwlq = nullptr, *dwloff = nullptr;
   uint64_t nwork = nitems;
-  double anchorms = 0;
   Timer tfirst(stream); // the first pass kernel (k_mum_first) alone
   // ragged batches take the same route with per-query geometry
   const uint64_t maxoffsets =
@@ -1073,305 +1067,170 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     index->lcpquirk = (b == 255) ? 1 : 0;
   }
-  // work plan (see k_mum_plan).  All of the work reduction rests on "a match
-  // that is not unique is no candidate"; the reference's test for lcp >= 255
+  // The work reduction (see k_mum_first, k_mum_plan) rests on "a match that
+  // is not unique is no candidate"; the reference's test for lcp >= 255
   // (fquery.c:352) breaks that rule in one situation, which one byte of
-  // lcptab rules out (see vsa_index::lcpquirk)
-  const bool planned = maxoffsets < 0xFFFFu && (index->tune & 4u) == 0;
-  // planned batches start with offset 0 (k_mum_first); the anchor pass from
-  // the last offset serves batches of equal-length queries only
-  firstpass = planned && (index->tune & 8u) == 0;
-  if (domum && maxoffsets > 1 && queries->nq < 0xFFFFFFFFull &&
-      (index->tune & 2u) == 0 &&
-      !(queries->maxlength >= 255 && index->lcpquirk != 0) &&
-      (qs.uniformlen != 0 || firstpass))
+  // lcptab rules out (see vsa_index::lcpquirk).  A plan holds 16-bit offsets.
+  // VSA_TUNE=2: no work reduction (every offset is searched by the list form
+  // of the search kernel -- the cross-check of everything below).
+  if (domum && maxoffsets > 1 && maxoffsets < 0xFFFFu &&
+      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0 &&
+      !(queries->maxlength >= 255 && index->lcpquirk != 0))
   {
     const uint64_t nq = queries->nq;
-    Timer tanchor(stream);
-    if (wcount.alloc((nq + 1) * 4) || wbase.alloc((nq + 1) * 8))
+    if (wcount.alloc((nq + 1) * 4) || wfirste.alloc(nq * 4) ||
+        wfmlen.alloc(nq * 4) || wfmdb.alloc(nq * 8) ||
+        wplan.alloc(nq * sizeof(PlanRanges)) || wlist.alloc(nq * 4))
     {
       return -100;
     }
-    tanchor.start();
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
-    if (firstpass)
+    tfirst.start();
+    if (deepok)
     {
-      if (wfirste.alloc(nq * 4) || wfmlen.alloc(nq * 4) ||
-          wfmdb.alloc(nq * 8))
+      // reads of one length m (a multiple of 4, <= 128), back to back:
+      // staged through LDS and packed
+      const bool staged = qs.dense != 0 && qs.uniformlen <= 128 &&
+                          (qs.uniformlen & 3u) == 0;
+      if (staged)
       {
-        return -100;
-      }
-      tfirst.start();
-      if (deepok)
-      {
-        {
-          // reads of one length m (a multiple of 4, <= 128), back to back:
-          // staged through LDS and packed (VSA_TUNE bit 7: without)
-          const bool staged = qs.dense != 0 && qs.uniformlen <= 128 &&
-                              (qs.uniformlen & 3u) == 0 &&
-                              (index->tune & 128u) == 0;
-          if (staged)
-          {
-            k_mum_first<IDX, true, true>
-                <<<gridfor(nq), VSA_BLOCK,
-                   (size_t) VSA_BLOCK * qs.uniformlen, stream>>>(
-                    ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
-                    wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
-                    wfmdb.as<uint64_t>());
-          } else
-          {
-            k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-                ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
-                wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
-                wfmdb.as<uint64_t>());
-          }
-        }
+        k_mum_first<IDX, true, true>
+            <<<gridfor(nq), VSA_BLOCK, (size_t) VSA_BLOCK * qs.uniformlen,
+               stream>>>(ix, qs, perquery, searchlength,
+                         wcount.as<uint32_t>(), wfirste.as<uint32_t>(),
+                         wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>());
       } else
       {
-        k_mum_first<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+        k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
             ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
             wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
             wfmdb.as<uint64_t>());
       }
-      tfirst.stop();
-    } else if (deepok)
-    {
-      k_mum_anchor<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-          ix, qs, perquery, searchlength, wcount.as<uint32_t>());
     } else
     {
-      k_mum_anchor<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-          ix, qs, perquery, searchlength, wcount.as<uint32_t>());
+      k_mum_first<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+          wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+          wfmdb.as<uint64_t>());
     }
+    tfirst.stop();
     VSA_HIP(hipGetLastError());
+    // the reads the first pass has not finished, as a list (counts per
+    // workgroup, a scan over the workgroups, an ordered fill); with it come
+    // the places of the first pass's candidates
+    uint64_t nlist = 0;
     size_t tb = 0;
-    // planned MUM batch on the deep tables: the search kernel reads the
-    // plans itself (k_query_search_planned) -- no scan over the queries, no
-    // work list, no read-back of its length (a workgroup size in VSA_TUNE bits
-    // 8-19, e.g. VSA_TUNE=256, selects the list form)
-    fromplan = planned && domum && deepok && qblock == 0;
-    if (planned)
     {
-      uint64_t nlist = 0;
-      // after the anchor pass only queries with many offsets left are worth
-      // a plan; after the first pass every unfinished query gets one
-      PlanWanted wanted{wcount.as<uint32_t>(),
-                        firstpass ? 0u : searchlength + 6};
-      if (wplan.alloc(nq * sizeof(PlanRanges)) || wlist.alloc(nq * 4))
+      // (queries < 2^32: the condition of this branch)
+      const uint64_t nb = blocksfor(nq), nbr = vsa_grid_blocks(nb);
+      DevBuf bcount;
+      if (bcount.alloc((nbr + 1) * 8) || wboffset.alloc((nbr + 1) * 8))
       {
         return -100;
       }
-      if (!firstpass)
-      {
-        // (after the first pass every query with work left is on the list
-        // and gets its plan from k_mum_plan; the others' are never used)
-        k_plan_default<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-            wcount.as<uint32_t>(), nq, wplan.as<PlanRanges>());
-        VSA_HIP(hipGetLastError());
-      }
-      {
-        // (queries < 2^32: the condition of this branch)
-        const uint64_t nb = blocksfor(nq), nbr = vsa_grid_blocks(nb);
-        const uint32_t threshold = wanted.threshold;
-        DevBuf bcount;
-        if (bcount.alloc((nbr + 1) * 8) || wboffset.alloc((nbr + 1) * 8))
-        {
-          return -100;
-        }
-        // (both halves of a count stay below 2^32: nq does)
-        VSA_HIP(hipMemsetAsync(bcount.as<uint64_t>() + nb, 0, 8, stream));
-        k_wanted_count<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
-            wcount.as<uint32_t>(), nq, threshold,
-            firstpass ? wfmlen.as<uint32_t>() : nullptr,
-            bcount.as<uint64_t>());
-        VSA_HIP(hipGetLastError());
-        VSA_HIP(rocprim::exclusive_scan(nullptr, tb, bcount.as<uint64_t>(),
-                                        wboffset.as<uint64_t>(), (uint64_t) 0,
-                                        (size_t) (nb + 1),
-                                        rocprim::plus<uint64_t>(), stream));
-        if (wtemp.alloc(tb))
-        {
-          return -100;
-        }
-        VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, bcount.as<uint64_t>(),
-                                        wboffset.as<uint64_t>(), (uint64_t) 0,
-                                        (size_t) (nb + 1),
-                                        rocprim::plus<uint64_t>(), stream));
-        k_wanted_fill<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
-            wcount.as<uint32_t>(), nq, threshold, wboffset.as<uint64_t>(),
-            wlist.as<uint32_t>());
-        VSA_HIP(hipGetLastError());
-        const Fetch f = {wboffset.as<uint64_t>() + nb, 8};
-        uint64_t both = 0;
-        if (fetchwords(stream, &f, 1, &both))
-        {
-          return -100;
-        }
-        nlist = both & 0xFFFFFFFFull;
-        nfirstpass = both >> 32;
-      }
-      if (nlist > 0)
-      {
-        // (VSA_PLAN_EMIT=0: the plan's own searches are repeated by the search
-        // kernel, as before round 2)
-        const char *noemit = getenv("VSA_PLAN_EMIT");
-        planemit = fromplan && firstpass &&
-                   !(noemit != nullptr && strcmp(noemit, "0") == 0);
-        if (planemit)
-        {
-          // room for every search A of the workgroups that share a region
-          const uint64_t nb = blocksfor(nlist),
-                         pershard = (nb + nshards - 1) / nshards;
-          pcap = pershard * VSA_BLOCK * (VSA_PLAN_ROUNDS - 1);
-          if (pcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
-              pdoff.alloc(nshards * 8) || psummary.alloc(4 * 8) ||
-              prawout.alloc(nshards * pcap * recsize) ||
-              prawkeys.alloc(nshards * pcap * 8))
-          {
-            return -100;
-          }
-          VSA_HIP(hipMemsetAsync(pcursor.p, 0,
-                                 (size_t) nshards * VSA_CURSOR_STRIDE * 8,
-                                 stream));
-          PlanEmit em;
-          em.base = dbase;
-          em.perquery = perquery;
-          em.out = prawout.as<vsa_match>();
-          em.outkey = prawkeys.as<uint64_t>();
-          em.shardcap = pcap;
-          em.shardmask = nshards - 1;
-          em.cursors = pcursor.as<unsigned long long>();
-          em.packbits = packbits;
-          em.valbits = valbits;
-          k_mum_plan<IDX, true, true>
-              <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-                  ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
-                  wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
-                  wplan.as<PlanRanges>(), em);
-          k_shard_summary<<<1, 1024, 0, stream>>>(
-              pcursor.as<unsigned long long>(), nshards,
-              pdoff.as<uint64_t>(), nullptr, nullptr,
-              psummary.as<uint64_t>());
-        } else if (deepok)
-        {
-          k_mum_plan<IDX, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-              ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
-              firstpass ? wfirste.as<uint32_t>() : nullptr,
-              wcount.as<uint32_t>(), wplan.as<PlanRanges>());
-        } else
-        {
-          k_mum_plan<IDX, false><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-              ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
-              firstpass ? wfirste.as<uint32_t>() : nullptr,
-              wcount.as<uint32_t>(), wplan.as<PlanRanges>());
-        }
-        VSA_HIP(hipGetLastError());
-      }
-      plansearches = 2 * nlist;
-      if (const char *pf = getenv("VSA_DEBUG_PLANFILE"))
-      {
-        // the plans of the first 65 536 queries as they stand when the search
-        // kernel starts -- per query its count and VSA_PLAN_RANGES ranges
-        // (first | length << 16), 32-bit words -- for bench.py, which prices
-        // the kernel on exactly the searches it runs
-        const uint64_t k = std::min<uint64_t>(nq, 65536);
-        std::vector<uint32_t> hc(k), hp(k * VSA_PLAN_RANGES);
-        VSA_HIP(hipMemcpyAsync(hc.data(), wcount.p, k * 4,
-                               hipMemcpyDeviceToHost, stream));
-        VSA_HIP(hipMemcpyAsync(hp.data(), wplan.p, k * sizeof(PlanRanges),
-                               hipMemcpyDeviceToHost, stream));
-        VSA_HIP(hipStreamSynchronize(stream));
-        if (FILE *f = fopen(pf, "wb"))
-        {
-          for (uint64_t q = 0; q < k; q++)
-          {
-            (void) fwrite(&hc[q], 4, 1, f);
-            (void) fwrite(&hp[q * VSA_PLAN_RANGES], 4, VSA_PLAN_RANGES, f);
-          }
-          fclose(f);
-        }
-      }
-      if (getenv("VSA_DEBUG_PLANHIST") != nullptr)
-      {
-        // how the work-items are spread over the planned reads (stderr)
-        std::vector<uint32_t> h(nq);
-        VSA_HIP(hipMemcpyAsync(h.data(), wcount.p, nq * 4,
-                               hipMemcpyDeviceToHost, stream));
-        VSA_HIP(hipStreamSynchronize(stream));
-        uint64_t hist[12] = {0}, total = 0, reads = 0;
-        for (uint64_t q = 0; q < nq; q++)
-        {
-          if (h[q] != 0)
-          {
-            hist[std::min<uint32_t>(h[q] / 8, 11)]++;
-            total += h[q];
-            reads++;
-          }
-        }
-        fprintf(stderr, "plan: %llu reads, %llu work-items;",
-                (unsigned long long) reads, (unsigned long long) total);
-        for (int b = 0; b < 12; b++)
-        {
-          fprintf(stderr, " %d-%d:%llu", 8 * b, 8 * b + 7,
-                  (unsigned long long) hist[b]);
-        }
-        fprintf(stderr, "\n");
-      }
-    }
-    if (fromplan)
-    {
-      tanchor.stop();
-    }
-    tb = 0;
-    auto widen = rocprim::make_transform_iterator(
-        wcount.as<uint32_t>(),
-        [] __device__(uint32_t v) { return (uint64_t) v; });
-    if (!fromplan)
-    {
-    VSA_HIP(rocprim::exclusive_scan(nullptr, tb, widen, wbase.as<uint64_t>(),
-                                    (uint64_t) 0, (size_t) (nq + 1),
-                                    rocprim::plus<uint64_t>(), stream));
-    if (wtemp.alloc(tb))
-    {
-      return -100;
-    }
-    VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, widen, wbase.as<uint64_t>(),
-                                    (uint64_t) 0, (size_t) (nq + 1),
-                                    rocprim::plus<uint64_t>(), stream));
-    {
-      const Fetch f = {wbase.as<uint64_t>() + nq, 8};
-      if (fetchwords(stream, &f, 1, &nwork))
+      // (both halves of a count stay below 2^32: nq does)
+      VSA_HIP(hipMemsetAsync(bcount.as<uint64_t>() + nb, 0, 8, stream));
+      k_wanted_count<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
+          wcount.as<uint32_t>(), nq, 0u, wfmlen.as<uint32_t>(),
+          bcount.as<uint64_t>());
+      VSA_HIP(hipGetLastError());
+      VSA_HIP(rocprim::exclusive_scan(nullptr, tb, bcount.as<uint64_t>(),
+                                      wboffset.as<uint64_t>(), (uint64_t) 0,
+                                      (size_t) (nb + 1),
+                                      rocprim::plus<uint64_t>(), stream));
+      if (wtemp.alloc(tb))
       {
         return -100;
       }
+      VSA_HIP(rocprim::exclusive_scan(wtemp.p, tb, bcount.as<uint64_t>(),
+                                      wboffset.as<uint64_t>(), (uint64_t) 0,
+                                      (size_t) (nb + 1),
+                                      rocprim::plus<uint64_t>(), stream));
+      k_wanted_fill<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
+          wcount.as<uint32_t>(), nq, 0u, wboffset.as<uint64_t>(),
+          wlist.as<uint32_t>());
+      VSA_HIP(hipGetLastError());
+      const Fetch f = {wboffset.as<uint64_t>() + nb, 8};
+      uint64_t both = 0;
+      if (fetchwords(stream, &f, 1, &both))
+      {
+        return -100;
+      }
+      nlist = both & 0xFFFFFFFFull;
+      nfirstpass = both >> 32;
     }
-    if (wlq.alloc(nwork * 4) || wloff.alloc(nwork * 4))
+    if (nlist > 0)
     {
-      return -100;
+      // on the deep tables the plan answers the offsets it locates itself
+      // (PlanEmit)
+      planemit = deepok;
+      if (planemit)
+      {
+        // room for every search A of the workgroups that share a region
+        const uint64_t nb = blocksfor(nlist),
+                       pershard = (nb + nshards - 1) / nshards;
+        pcap = pershard * VSA_BLOCK * (VSA_PLAN_ROUNDS - 1);
+        if (pcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
+            pdoff.alloc(nshards * 8) || psummary.alloc(4 * 8) ||
+            prawout.alloc(nshards * pcap * recsize) ||
+            prawkeys.alloc(nshards * pcap * 8))
+        {
+          return -100;
+        }
+        VSA_HIP(hipMemsetAsync(pcursor.p, 0,
+                               (size_t) nshards * VSA_CURSOR_STRIDE * 8,
+                               stream));
+        PlanEmit em;
+        em.base = dbase;
+        em.perquery = perquery;
+        em.out = prawout.as<vsa_match>();
+        em.outkey = prawkeys.as<uint64_t>();
+        em.shardcap = pcap;
+        em.shardmask = nshards - 1;
+        em.cursors = pcursor.as<unsigned long long>();
+        em.packbits = packbits;
+        em.valbits = valbits;
+        k_mum_plan<IDX, true, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+            ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+            wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
+            wplan.as<PlanRanges>(), em);
+        k_shard_summary<<<1, 1024, 0, stream>>>(
+            pcursor.as<unsigned long long>(), nshards, pdoff.as<uint64_t>(),
+            nullptr, nullptr, psummary.as<uint64_t>());
+      } else
+      {
+        k_mum_plan<IDX, false><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+            ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+            wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
+            wplan.as<PlanRanges>());
+      }
+      VSA_HIP(hipGetLastError());
     }
-    if (planned)
+    plansearches = 2 * nlist;
+    if (const char *pf = getenv("VSA_DEBUG_PLANFILE"))
     {
-      k_expand_plan<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-          wplan.as<PlanRanges>(), wbase.as<uint64_t>(), nq,
-          wlq.as<uint32_t>(), wloff.as<uint32_t>());
-    } else
-    {
-      k_expand_worklist<<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
-          wcount.as<uint32_t>(), wbase.as<uint64_t>(), nq,
-          wlq.as<uint32_t>(), wloff.as<uint32_t>());
+      // the plans of the first 65 536 queries as they stand when the search
+      // kernel starts -- per query its count and VSA_PLAN_RANGES ranges
+      // (first | length << 16), 32-bit words -- for bench.py, which prices
+      // the kernel on exactly the searches it runs
+      const uint64_t k = std::min<uint64_t>(nq, 65536);
+      std::vector<uint32_t> hc(k), hp(k * VSA_PLAN_RANGES);
+      VSA_HIP(hipMemcpyAsync(hc.data(), wcount.p, k * 4,
+                             hipMemcpyDeviceToHost, stream));
+      VSA_HIP(hipMemcpyAsync(hp.data(), wplan.p, k * sizeof(PlanRanges),
+                             hipMemcpyDeviceToHost, stream));
+      VSA_HIP(hipStreamSynchronize(stream));
+      if (FILE *f = fopen(pf, "wb"))
+      {
+        for (uint64_t q = 0; q < k; q++)
+        {
+          (void) fwrite(&hc[q], 4, 1, f);
+          (void) fwrite(&hp[q * VSA_PLAN_RANGES], 4, VSA_PLAN_RANGES, f);
+        }
+        fclose(f);
+      }
     }
-    VSA_HIP(hipGetLastError());
-    tanchor.stop();
-    VSA_HIP(hipStreamSynchronize(stream));
-    anchorms = tanchor.ms();
-    dwlq = wlq.as<uint32_t>();
-    dwloff = wloff.as<uint32_t>();
-    } // !fromplan
-    res->stats.searches = nwork + nq + plansearches;
-  }
-  if (dwlq == nullptr && !fromplan)
-  {
-    firstpass = false; // the work reduction was not entered
+    fromplan = true;
   }
   DevBuf doff, rawout, rawkeys, summary, blocksum, rtemp;
   const uint64_t nplanblocks = (queries->nq + 255) / 256;
@@ -1408,32 +1267,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       std::max<uint64_t>((queries->nq * 2 / nshards) * 5 / 4 + 64, 256);
   uint64_t needed = 0, maxshard = 0;
   double searchms = 0;
-  // MUM search on the deep tables, VSA_TUNE bit 6 (experiment, off by
-  // default): work-items whose matched length needs the text (true matches, 3
-  // in 100) go to a list and get a kernel of their own (k_query_deferred).  A
-  // region of the list holds every item of the workgroups that write to it,
-  // so it cannot overflow.  Measured in round 2 (profiles/r02/
-  // k2_deferral_ab.txt): the search kernel loses a third of its vector memory
-  // instructions and 8 % of its time, the second kernel takes that back.
-  const unsigned int qblk =
-      (qblock == 64 || qblock == 128 || qblock == 512) ? (unsigned) qblock
-                                                        : 256u;
-  const uint64_t nblocksq = (nwork + qblk - 1) / qblk,
-                 defcap = ((nblocksq + nshards - 1) / nshards) * qblk;
-  bool defer = false;
-  if constexpr (sizeof(IDX) == 4)
-  {
-    defer = domum && deepok && nwork > 0 && (index->tune & 64u) != 0 &&
-            queries->maxlength < 0xFFFFu && queries->nq < 0xFFFFFFFFull &&
-            nshards * defcap * 20 <= (8ull << 30);
-  }
-  DevBuf defrec, defw, defcursor;
-  if (defer && (defrec.alloc(nshards * defcap * sizeof(DeferredSearch)) ||
-                defw.alloc(nshards * defcap * 4) ||
-                defcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8)))
-  {
-    return -100;
-  }
   for (int attempt = 0; attempt < 2; attempt++)
   {
     if (rawout.alloc(nshards * shardcap * recsize) ||
@@ -1443,133 +1276,50 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipMemsetAsync(cursor.p, 0,
                            (size_t) nshards * VSA_CURSOR_STRIDE * 8, stream));
-    if (defer)
-    {
-      VSA_HIP(hipMemsetAsync(defcursor.p, 0,
-                             (size_t) nshards * VSA_CURSOR_STRIDE * 8,
-                             stream));
-    }
-    // experiment switch: VSA_K2_LDS bytes of unused dynamic LDS per workgroup
-    // cut the resident wavefronts (occupancy sweeps, profiles/r02)
-    const char *ldsenv = getenv("VSA_K2_LDS");
-    const size_t k2lds = ldsenv != nullptr ? (size_t) atol(ldsenv) : 0;
     tsearch.start();
-#define VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, BLK)                              \
-  k_query_search<IDX, MUMFLAG, KEYFLAG, BLK>                                  \
-      <<<vsa_grid((nwork + BLK - 1) / BLK), BLK, k2lds, stream>>>(            \
-          ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
+#define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
+  k_query_search<IDX, MUMFLAG, KEYFLAG, 256>                                  \
+      <<<vsa_grid((nwork + 255) / 256), 256, 0, stream>>>(                    \
+          ix, qs, dbase, perquery, nwork, searchlength,                       \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
-#define VSA_LAUNCH_QUERY(MUMFLAG, KEYFLAG)                                     \
-  do                                                                          \
-  {                                                                           \
-    if (qblock == 64)                                                         \
-    {                                                                         \
-      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 64);                               \
-    } else if (qblock == 128)                                                 \
-    {                                                                         \
-      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 128);                              \
-    } else if (qblock == 512)                                                 \
-    {                                                                         \
-      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 512);                              \
-    } else                                                                    \
-    {                                                                         \
-      VSA_LAUNCH_QUERY_B(MUMFLAG, KEYFLAG, 256);                              \
-    }                                                                         \
-  } while (0)
-    // deep locate needs the deep prefix to fit into every search
-    bool deep = nwork == 0; // nothing left to search: no launch at all
+    if (fromplan && deepok)
     {
-      deep = deep || deepok;
-      if (fromplan)
-      {
-        // VSA_K2_TWOPHASE=1 (experiment, fused 16-byte slots): work-items
-        // the slot finishes leave after one round trip, the others are
-        // compacted per wavefront (k_query_search_planned2).  Round 2, same
-        // box: 1.74 ms against 1.50-1.55 ms for the one-phase kernel.
-        const char *twophase = getenv("VSA_K2_TWOPHASE");
-        if (ix.slot16 != nullptr && ix.slotwords == 2 && twophase != nullptr &&
-            strcmp(twophase, "1") == 0)
-        {
-          k_query_search_planned2<IDX, 256>
-              <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
-                  ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
-                  wcount.as<uint32_t>(), searchlength,
-                  rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
-                  nshards - 1, cursor.as<unsigned long long>(), packbits,
-                  valbits, blocksum.as<unsigned long long>());
-        } else
-        {
-          k_query_search_planned<IDX, 256>
-              <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
-                  ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
-                  wcount.as<uint32_t>(), searchlength,
-                  rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,
-                  nshards - 1, cursor.as<unsigned long long>(), packbits,
-                  valbits, blocksum.as<unsigned long long>());
-        }
-      } else if (deep && nwork > 0)
-      {
-        bool deferred = false;
-        if constexpr (sizeof(IDX) == 4) // (the experiment has 32-bit records)
-        {
-          deferred = domum && defer;
-        }
-        if (deferred)
-        {
-          if constexpr (sizeof(IDX) == 4)
-          {
-#define VSA_LAUNCH_DEFER(BLK)                                                  \
-  k_query_search<IDX, true, true, BLK, true>                                  \
-      <<<vsa_grid(nblocksq), BLK, k2lds, stream>>>(                           \
-          ix, qs, dbase, perquery, dwlq, dwloff, nwork, searchlength,         \
-          rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
-          nshards - 1, cursor.as<unsigned long long>(), packbits, valbits,    \
-          defrec.as<DeferredSearch>(), defw.as<uint32_t>(), defcap,           \
-          defcursor.as<unsigned long long>())
-          if (qblk == 64)
-          {
-            VSA_LAUNCH_DEFER(64);
-          } else if (qblk == 128)
-          {
-            VSA_LAUNCH_DEFER(128);
-          } else if (qblk == 512)
-          {
-            VSA_LAUNCH_DEFER(512);
-          } else
-          {
-            VSA_LAUNCH_DEFER(256);
-          }
-#undef VSA_LAUNCH_DEFER
-          VSA_HIP(hipGetLastError());
-          k_query_deferred<256><<<nshards, 256, 0, stream>>>(
-              ix, qs, dbase, perquery, searchlength,
-              defrec.as<DeferredSearch>(), defw.as<uint32_t>(), defcap,
-              defcursor.as<unsigned long long>(), rawout.as<vsa_match>(),
-              rawkeys.as<uint64_t>(), shardcap,
-              cursor.as<unsigned long long>(), packbits, valbits);
-          }
-        } else if (domum)
-        {
-          VSA_LAUNCH_QUERY(true, true);
-        } else
-        {
-          VSA_LAUNCH_QUERY(false, true);
-        }
-      }
-    }
-    if (!deep)
+      k_query_search_planned<IDX, 256, true>
+          <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
+              ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+              wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
+              rawkeys.as<uint64_t>(), shardcap, nshards - 1,
+              cursor.as<unsigned long long>(), packbits, valbits,
+              blocksum.as<unsigned long long>());
+    } else if (fromplan)
     {
-      if (domum)
+      k_query_search_planned<IDX, 256, false>
+          <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
+              ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+              wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
+              rawkeys.as<uint64_t>(), shardcap, nshards - 1,
+              cursor.as<unsigned long long>(), packbits, valbits,
+              blocksum.as<unsigned long long>());
+    } else if (nwork > 0)
+    {
+      // every (query, offset) pair: MEM, and MUM batches without a plan
+      // (deep locate needs the deep prefix to fit into every search)
+      if (domum && deepok)
+      {
+        VSA_LAUNCH_QUERY(true, true);
+      } else if (domum)
       {
         VSA_LAUNCH_QUERY(true, false);
+      } else if (deepok)
+      {
+        VSA_LAUNCH_QUERY(false, true);
       } else
       {
         VSA_LAUNCH_QUERY(false, false);
       }
     }
 #undef VSA_LAUNCH_QUERY
-#undef VSA_LAUNCH_QUERY_B
     tsearch.stop();
     VSA_HIP(hipGetLastError());
     if (fromplan)
@@ -1601,7 +1351,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       nplan = planemit ? got[5] : 0;
       needed = got[0];
       maxshard = got[1];
-      nfirst = firstpass ? nfirstpass : 0;
+      nfirst = fromplan ? nfirstpass : 0;
       plannedwork = fromplan ? got[4] : 0;
     }
     searchms += tsearch.ms();
@@ -1745,7 +1495,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   VSA_HIP(hipStreamSynchronize(stream));
   res->stats.count = res->count;
   res->stats.search_kernel_ms = searchms;
-  res->stats.anchor_ms = anchorms;
+  res->stats.anchor_ms = 0; // (the anchor pass of round 1 is gone)
   res->stats.first_kernel_ms = tfirst.ms();
   if (fromplan)
   {
@@ -2142,35 +1892,18 @@ int vsa_index_make_esa8(vsa_index *ix)
   // allocated FIRST, with the temporaries of the builder handed back to the
   // driver.  Placed last, between what the builder had left, the 68.7 GB of a
   // 3 Gbp index were mapped in small pages and a random read of it cost a read
-  // of the page table on top: 38 G reads/s against 77 G for every other table
-  // (scripts/table_read_probe.py, profiles/r03/table_read_probe.txt).
-  // (VSA_SLOT_ALLOC_LAST=1: the old order)
-  const char *slotenv = getenv("VSA_SLOT");
-  int slotbytes = slotenv != nullptr ? atoi(slotenv) : 16;
-  if (slotbytes != 0 && slotbytes != 16 && slotbytes != 32)
+  // of the page table on top (profiles/r03/table_read_probe.txt).
+  VSA_HIP(hipStreamSynchronize(ix->stream));
+  vsa_dev_trim();
+  if (vsa_hip_malloc((void **) &ix->slot16, 2 * ncodes * 8 + 32) != hipSuccess)
   {
-    slotbytes = 16;
+    // no room for it (VSA_DEEP_PREFIX asked for more than fits): this index
+    // is searched the reference's way
+    (void) hipGetLastError();
+    ix->slot16 = nullptr;
+    ix->D = 0;
+    return 0;
   }
-  if (wide && slotbytes == 0)
-  {
-    slotbytes = 16; // wide tables have the fused form only
-  }
-  {
-    const char *last = getenv("VSA_SLOT_ALLOC_LAST");
-    if (slotbytes != 0 && !(last != nullptr && strcmp(last, "1") == 0))
-    {
-      VSA_HIP(hipStreamSynchronize(ix->stream));
-      vsa_dev_trim();
-      if (vsa_hip_malloc((void **) &ix->slot16,
-                         (uint64_t) (slotbytes / 8) * ncodes * 8 + 32) !=
-          hipSuccess)
-      {
-        (void) hipGetLastError();
-        ix->slot16 = nullptr; // (tried again below, smaller if need be)
-      }
-    }
-  }
-  const int slotbytesfirst = slotbytes;
   VSA_HIP(vsa_hip_malloc((void **) &ix->bck2, 2 * ncodes * ix->isize + 16));
   VSA_HIP(vsa_hip_malloc((void **) &ix->esa8, count * 8 + 64));
   ix->device_bytes += count * 8 + 2 * ncodes * ix->isize;
@@ -2196,9 +1929,7 @@ int vsa_index_make_esa8(vsa_index *ix)
   }
   VSA_HIP(hipGetLastError());
   VSA_HIP(hipStreamSynchronize(ix->stream));
-  // the 2-bit text for long comparisons (VSA_PACKED_TEXT=0: without)
-  const char *nopack = getenv("VSA_PACKED_TEXT");
-  if (!(nopack != nullptr && strcmp(nopack, "0") == 0))
+  // the 2-bit text for long comparisons
   {
     // blocks 0 .. n >> 6: a comparison ends at position n at the latest (the
     // last block reads into the 0xFF padding behind the text, not beyond it)
@@ -2226,49 +1957,20 @@ int vsa_index_make_esa8(vsa_index *ix)
   }
   // the fused table takes the place of bck2: 16 bytes per deep prefix (bounds
   // + the first entry: 69 % of the non-empty buckets of a random text are
-  // answered by one access; 68.7 GB at 3 Gbp); VSA_SLOT=32: 32 bytes (bounds +
-  // three entries: 99 %; 137 GB -- measured in round 2: 20 % fewer HBM
-  // sectors in the search kernel and not a microsecond less, because a
-  // second 16-byte load of the same sector is a request of its own and the
-  // kernel is bound by requests in flight, profiles/r02/slot32_ab.txt);
-  // VSA_SLOT=0 keeps bck2.  A wide form is dropped when memory is short.
+  // answered by one access; 68.7 GB at 3 Gbp).  (32-byte slots with three
+  // entries were measured in round 2, profiles/r02/slot32_ab.txt, and read
+  // again in round 4, profiles/r04/README.md: fewer HBM lines, but a second
+  // load instruction per lane.)
   unsigned int *dtoobig = nullptr, htoobig = 0;
   VSA_HIP(vsa_hip_malloc((void **) &dtoobig, 4));
   VSA_HIP(hipMemsetAsync(dtoobig, 0, 4, ix->stream));
-  for (; slotbytes >= 16; slotbytes -= 16)
   {
-    const uint32_t words = (uint32_t) slotbytes / 8;
-    if (ix->slot16 != nullptr && slotbytes != slotbytesfirst)
-    {
-      (void) hipFree(ix->slot16); // (cannot happen: it was there in time)
-      ix->slot16 = nullptr;
-    }
-    if (ix->slot16 == nullptr &&
-        vsa_hip_malloc((void **) &ix->slot16, words * ncodes * 8 + 32) !=
-            hipSuccess)
-    {
-      (void) hipGetLastError();
-      ix->slot16 = nullptr;
-      continue;
-    }
     const unsigned int grid = (unsigned int) std::min<uint64_t>(
         (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20);
     if (wide)
     {
-      const uint64_t *pairs = (const uint64_t *) ix->bck2;
-      if (words == 4)
-      {
-        k_make_slots<4, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-            pairs, ix->esa8, ncodes, ix->slot16, dtoobig);
-      } else
-      {
-        k_make_slots<2, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-            pairs, ix->esa8, ncodes, ix->slot16, dtoobig);
-      }
-    } else if (words == 4)
-    {
-      k_make_slots<4, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-          ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
+      k_make_slots<2, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          (const uint64_t *) ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
     } else
     {
       k_make_slots<2, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
@@ -2280,24 +1982,17 @@ int vsa_index_make_esa8(vsa_index *ix)
     VSA_HIP(hipStreamSynchronize(ix->stream));
     (void) hipFree(ix->bck2);
     ix->bck2 = nullptr;
-    ix->slotwords = words;
-    ix->device_bytes += (uint64_t) words * ncodes * 8 - 2 * ncodes * ix->isize;
-    break;
+    ix->slotwords = 2;
+    ix->device_bytes += 2 * ncodes * 8 - 2 * ncodes * ix->isize;
   }
   (void) hipFree(dtoobig);
-  if (wide && (ix->slot16 == nullptr || htoobig != 0))
+  if (wide && htoobig != 0)
   {
-    // no room for the fused table, or a deep bucket with 2^24 suffixes or
-    // more: this index is searched the reference's way
+    // a deep bucket with 2^24 suffixes or more: this index is searched the
+    // reference's way
     const uint64_t nblocks = (ix->n >> 6) + 1, nwaves = (nblocks + 63) / 64;
     ix->device_bytes -= count * 8;
-    if (ix->slot16 != nullptr)
-    {
-      ix->device_bytes -= (uint64_t) ix->slotwords * ncodes * 8;
-    } else
-    {
-      ix->device_bytes -= 2 * ncodes * ix->isize;
-    }
+    ix->device_bytes -= (uint64_t) ix->slotwords * ncodes * 8;
     if (ix->tis2 != nullptr)
     {
       ix->device_bytes -= nblocks * 16 + nwaves * 8;
@@ -3014,13 +2709,9 @@ int partition_impl(const vsa_result *result, uint32_t nparts, int ownpart,
     }
     return 0;
   }
-  // tiles of eight records per lane for pairs that go to up to 8 parts
-  // (VSA_PARTITION_SMALL=0: the general kernels, for comparison)
-  static const bool smallok = []() {
-    const char *e = getenv("VSA_PARTITION_SMALL");
-    return e == nullptr || atoi(e) != 0;
-  }();
-  const bool small = smallok && nparts <= VSA_PT_SMALL &&
+  // tiles of eight records per lane for pairs that go to up to 8 parts (the
+  // general kernels take records, and more parts)
+  const bool small = nparts <= VSA_PT_SMALL &&
                      result->packbits != 0;
   const uint64_t nblocks =
                      small ? (n + VSA_PT_TILE - 1) / VSA_PT_TILE
