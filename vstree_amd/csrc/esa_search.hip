@@ -1519,15 +1519,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
 
 // ---- K3 pipeline ----
 
-// VSA_PEAKVARIANT (experiments): bit 0 = nontemporal loads, bit 1 = tiles of
-// 2 instead of 4 pieces.  Measured at 3 Gbp (dense case, 1024 workgroups):
-// 1.13 ms plain, 1.09 ms nontemporal, 1.40 / 1.35 ms with 2 pieces.
-static int vsa_peakvariant(void)
-{
-  const char *e = getenv("VSA_PEAKVARIANT");
-  return (e != NULL) ? atoi(e) & 3 : 1;
-}
-
 // workgroups of the streaming pass: 4 per CU = all the wavefronts that fit
 // with 100 VGPRs each, every one walking its tiles grid-stride
 // (VSA_PEAKBLOCKS overrides, for experiments)
@@ -1535,7 +1526,7 @@ static uint64_t vsa_peakblocks(void)
 {
   const char *e = getenv("VSA_PEAKBLOCKS");
   const long v = (e != NULL) ? atol(e) : 0;
-  return v > 0 ? (uint64_t) v : 1024;
+  return v > 0 ? (uint64_t) v : 0;
 }
 
 // [first, last) = the values of the reference's loop variable i
@@ -1550,8 +1541,11 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   const DevIndex<IDX> ix = index->view<IDX>();
   const uint64_t n = index->n;
   const uint32_t nshards = VSA_CURSOR_SHARDS;
-  const int variant = vsa_peakvariant();
-  const uint64_t pieces = (variant & 2) ? 2 : 4, tilesize = 64 * pieces * 16;
+  // VSA_PEAK_ROLLING=W (experiment of round 4): the one-tile kernel at W
+  // wavefronts per SIMD; 0: the two-tile kernel of round 3
+  const char *rollenv = getenv("VSA_PEAK_ROLLING");
+  const int rolling = rollenv != nullptr ? atoi(rollenv) : 0;
+  const uint64_t pieces = 4, tilesize = 64 * pieces * 16;
   // centres j = i - 1
   const uint64_t jlo = std::max<uint64_t>(first, 2) - 1,
                  jhi = std::max<uint64_t>(std::min<uint64_t>(last, n), 2) - 1;
@@ -1561,7 +1555,10 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   const uint64_t nblocks = std::max<uint64_t>(
       1, std::min<uint64_t>((ntiles - tile0 + wavesperblock - 1) /
                                 wavesperblock,
-                            (uint64_t) vsa_peakblocks()));
+                            vsa_peakblocks() != 0
+                                ? vsa_peakblocks()
+                                : (uint64_t) 256 * (rolling > 0 ? rolling
+                                                                : 4)));
   const uint32_t slmin = (uint32_t) (searchlength < 255 ? searchlength : 255);
   DevBuf cursor, doff, rawpos, peaks, sorted, temp, cand, keep, dcount, mums;
   uint64_t shardcap =
@@ -1593,13 +1590,20 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
                                      stream>>>(                               \
       ix.lcp, ix.bwt, n, slmin, rawpos.as<IDX>(), shardcap, nshards - 1,      \
       cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi)
-    switch (variant)
+#define VSA_PEAKS_ROLLING(WAVES)                                              \
+  k_selfmum_peaks_rolling<true, IDX, WAVES>                                   \
+      <<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(                     \
+          ix.lcp, ix.bwt, n, slmin, rawpos.as<IDX>(), shardcap, nshards - 1,  \
+          cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi)
+    switch (rolling)
     {
-      case 1: VSA_PEAKS(4, true); break;
-      case 2: VSA_PEAKS(2, false); break;
-      case 3: VSA_PEAKS(2, true); break;
-      default: VSA_PEAKS(4, false); break;
+      case 4: VSA_PEAKS_ROLLING(4); break;
+      case 5: VSA_PEAKS_ROLLING(5); break;
+      case 6: VSA_PEAKS_ROLLING(6); break;
+      case 8: VSA_PEAKS_ROLLING(8); break;
+      default: VSA_PEAKS(4, true); break;
     }
+#undef VSA_PEAKS_ROLLING
 #undef VSA_PEAKS
     tsearch.stop();
     VSA_HIP(hipGetLastError());
