@@ -96,6 +96,10 @@ def parse():
                     help="queries timed on one CPU core (0 = no CPU baseline)")
     ap.add_argument("--ref-sample", type=int, default=2000000,
                     help="queries given to the P reference processes together")
+    ap.add_argument("--reads", choices=("packed", "bytes"), default="bytes",
+                    help="how the query batch lies in HBM: the reference's "
+                         "Multiseq bytes, or two bits per symbol "
+                         "(vsa_pack_reads)")
     ap.add_argument("--quick", action="store_true",
                     help="headline step and its roofline only")
     ap.add_argument("--no-reference", action="store_true",
@@ -656,6 +660,12 @@ def main():
                                             sub.ctypes.data,
                                             step.ctypes.data, nq, m, dq, dev))
     queries = V.Queries.from_device(dq, nq, m, dev)
+    if a.reads == "packed":
+        hq = np.empty(nq * m, np.uint8)
+        V.device_download(hq, dq, dev)
+        queries.close()
+        queries = V.Queries.from_host_packed(hq, m, dev)
+        del hq
     queries.set_offset(rank * nq)
     V.device_free(dq, dev)
     extras = rank == 0 and world == 1 and not a.quick
@@ -817,6 +827,12 @@ def main():
                    "minlen": L, "prefixlength": info.prefixlength,
                    "index_bytes_hbm": info.device_bytes,
                    "index_build_s": round(t_index, 2),
+                   "reads_in_hbm": ("two bits per symbol, %d bytes per read "
+                                    "(vsa_pack_reads)"
+                                    % (V.lib.vsa_packed_words(m) * 8)
+                                    if a.reads == "packed" else
+                                    "one byte per symbol (the reference's "
+                                    "Multiseq)"),
                    "parallelism": "index replicated, queries sharded x%d"
                                   % world},
         "gbp_matched_per_s": sumlength * a.steps / elapsed / 1e9
@@ -1079,72 +1095,111 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
 def end_to_end(V, index, dg, n, nq, m, L, dev):
     """queries in (page-locked) host memory -> matches in host memory through
     vsa_pipeline_*: three batches in flight, upload / search / download
-    overlapped.  Two jobs: `-mum` over 3 different batches (30 M reads; the
-    global filter over all candidates and the download of the MUM list are
-    inside the timed region), and `-mum cand` in steady state (12 batches,
-    every batch's list downloaded).  The page-locked buffers are filled
-    before the clock starts (a slot keeps its reads between jobs): what is
-    timed is host memory -> host memory, not the production of the reads."""
+    overlapped.  The reads travel at two bits per symbol (vsa_pack_reads into
+    the slots' rows: 32 bytes per 100 bp read instead of 100).  Two jobs:
+    `-mum` over 3 different batches (30 M reads; the global filter over all
+    candidates and the download of the MUM list are inside the timed region),
+    and `-mum cand` in steady state (12 batches, every batch's list
+    downloaded).  The page-locked rows are filled before the clock starts (a
+    slot keeps its reads between jobs): what is timed is host memory -> host
+    memory, not the production of the reads; the packer's own rate (one host
+    thread) is reported next to it.  `bytes`: the same two jobs with the reads
+    as bytes (the form of round 3), for comparison."""
     pos, sub, step = V.synth_query_plan(n, 3 * nq, m, seed=777)
     dq = V.device_malloc(nq * m + 64, dev)
+    hbuf = np.empty(nq * m, np.uint8)
 
-    def fill(buf, b):
+    def reads(b):
         sl = slice(b * nq, (b + 1) * nq)
         ps, sb, st = (np.ascontiguousarray(x[sl]) for x in (pos, sub, step))
         V._check(V.lib.vsa_synth_queries_device(
             dg, n, ps.ctypes.data, sb.ctypes.data, st.ctypes.data, nq, m, dq,
             dev))
-        V.device_download(buf[:nq * m], dq, dev)
+        V.device_download(hbuf, dq, dev)
+        return hbuf
+
+    packrate = [0.0]
 
     def job(p, batches, refill):
         sub_, got, total = 0, 0, 0
         while got < batches:
-            buf = p.hostbuffer() if sub_ < batches else None
-            if buf is not None:
-                if refill:
-                    fill(buf, sub_ % 3)
-                p.submit(nq)
+            slot = None
+            if sub_ < batches:
+                slot = p.hostrows() if p.packed else p.hostbuffer()
+            if slot is not None:
+                if p.packed:
+                    rows, special = slot
+                    key = rows.ctypes.data
+                    if refill:
+                        ns = C.c_uint64(0)
+                        src = reads(sub_ % 3)
+                        t0 = time.perf_counter()
+                        V._check(V.lib.vsa_pack_reads(
+                            src.ctypes.data, nq, m, m, rows.ctypes.data,
+                            special.ctypes.data, p.maxspecial, C.byref(ns)))
+                        packrate[0] = nq / (time.perf_counter() - t0)
+                        job.ns[key] = int(ns.value)
+                    V._check(V.lib.vsa_pipeline_submit_packed(
+                        p._h, nq, job.ns[key]))
+                else:
+                    if refill:
+                        slot[:nq * m] = reads(sub_ % 3)
+                    p.submit(nq)
                 sub_ += 1
             else:
                 rc, mm = p.next(copy=False)
                 total += len(mm)
                 got += 1
         return total
+    job.ns = {}
 
-    out = {}
-    p = V.Pipeline(index, 3, L, m, nq)
-    job(p, 3, True)                    # fills the three slots, warms up
-    p.finish()
-    t0 = time.perf_counter()
-    job(p, 3, False)
-    t1 = time.perf_counter()
-    mums, st = p.finish(copy=False)   # a view of the page-locked list
-    dt = time.perf_counter() - t0
-    nmums = int(len(mums))
-    log("end to end -mum: batches %.1f ms, filter + list to the host %.1f ms"
-        % ((t1 - t0) * 1e3, (dt - (t1 - t0)) * 1e3))
-    p.close()
-    out["mum"] = {
-        "end_to_end_queries_per_s": 3 * nq / dt, "queries": 3 * nq,
-        "ms": dt * 1e3, "mums": nmums,
-        "candidates": int(st.candidates),
-        "what": "vmatch -mum -l %d: 3 batches of %d reads from page-locked "
-                "host memory (%.2f GB each over PCIe) to the MUM list of the "
-                "whole job in host memory (%.2f GB), global filter included"
-                % (L, nq, nq * m / 1e9, nmums * 32 / 1e9)}
-    p = V.Pipeline(index, 2, L, m, nq)
-    job(p, 3, True)
-    t0 = time.perf_counter()
-    total = job(p, 12, False)
-    dt = time.perf_counter() - t0
-    p.close()
-    out["mumcand"] = {
-        "end_to_end_queries_per_s": 12 * nq / dt, "queries": 12 * nq,
-        "ms_per_batch": dt / 12 * 1e3, "matches": int(total),
-        "what": "vmatch -mum cand -l %d: 12 batches of %d reads, every "
-                "batch's candidate list (%.2f GB) back in host memory"
-                % (L, nq, total / 12 * 32 / 1e9)}
-    out["end_to_end_queries_per_s"] = out["mum"]["end_to_end_queries_per_s"]
+    def both(packed):
+        out = {}
+        p = V.Pipeline(index, 3, L, m, nq, packed=packed, maxspecial=1024)
+        job(p, 3, True)                    # fills the three slots, warms up
+        p.finish()
+        t0 = time.perf_counter()
+        job(p, 3, False)
+        t1 = time.perf_counter()
+        mums, st = p.finish(copy=False)   # a view of the page-locked list
+        dt = time.perf_counter() - t0
+        nmums = int(len(mums))
+        log("end to end -mum (%s): batches %.1f ms, filter + list to the "
+            "host %.1f ms" % ("packed" if packed else "bytes",
+                              (t1 - t0) * 1e3, (dt - (t1 - t0)) * 1e3))
+        p.close()
+        up = nq * (V.lib.vsa_packed_words(m) * 8 if packed else m)
+        out["mum"] = {
+            "end_to_end_queries_per_s": 3 * nq / dt, "queries": 3 * nq,
+            "ms": dt * 1e3, "mums": nmums,
+            "candidates": int(st.candidates),
+            "what": "vmatch -mum -l %d: 3 batches of %s reads from "
+                    "page-locked host memory (%.2f GB each over PCIe) to the "
+                    "MUM list of the whole job in host memory (%.2f GB), "
+                    "global filter included"
+                    % (L, human(nq), up / 1e9, nmums * 32 / 1e9)}
+        p = V.Pipeline(index, 2, L, m, nq, packed=packed, maxspecial=1024)
+        job(p, 3, True)
+        t0 = time.perf_counter()
+        total = job(p, 12, False)
+        dt = time.perf_counter() - t0
+        p.close()
+        out["mumcand"] = {
+            "end_to_end_queries_per_s": 12 * nq / dt, "queries": 12 * nq,
+            "ms_per_batch": dt / 12 * 1e3, "matches": int(total),
+            "what": "vmatch -mum cand -l %d: 12 batches of %s reads (%.2f GB "
+                    "up each), every batch's candidate list (%.2f GB) back "
+                    "in host memory"
+                    % (L, human(nq), up / 1e9, total / 12 * 32 / 1e9)}
+        out["end_to_end_queries_per_s"] = \
+            out["mum"]["end_to_end_queries_per_s"]
+        return out
+
+    out = both(True)
+    out["reads"] = "two bits per symbol (vsa_pack_reads, %d bytes per read)" \
+        % (V.lib.vsa_packed_words(m) * 8)
+    out["pack_reads_per_s_one_host_thread"] = packrate[0]
+    out["bytes"] = both(False)
     V.device_free(dq, dev)
     return out
 

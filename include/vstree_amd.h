@@ -177,6 +177,41 @@ int vsa_queries_from_host(const uint8_t *symbols, uint64_t nsymbols,
 int vsa_queries_from_device(const void *device_symbols, uint64_t nq,
                             uint32_t m, int device, vsa_queries **queries);
 
+/*
+  Reads at two bits per symbol: what crosses PCIe and lies in HBM for a batch
+  of short reads of ONE length m is a quarter of the Multiseq's bytes.
+    row of read i = words [i * W, (i + 1) * W) of `rows`, W =
+      vsa_packed_words(m) = ceil((2 m + 8) / 64) 64-bit words; symbol j in
+      bits 63 - 2 (j mod 32), 62 - 2 (j mod 32) of word j / 32 -- the first
+      symbol in the top bits, codes a 0, c 1, g 2, t 3 as the DNA symbol map
+      assigns them (kurtz-basic/alphabet.c:369, `mkvtree -dna`); every other
+      bit 0, except the lowest byte of the last word, the row's flag:
+        0  all m symbols are bases
+        1  the read holds a special symbol (a wildcard, kurtz/maxpref.c:30-41:
+           it matches nothing, not even itself): the row's symbol bits are
+           ignored, word 0 = k names entry k of `special`, the read's m
+           mapped symbols as bytes at special + k * m.
+  vsa_pack_reads makes rows (and the side list) from numofqueries reads of m
+  mapped symbols, read i at symbols + i * stride (stride = m: back to back;
+  m + 1: a Multiseq with its separators); *numofspecial counts the entries of
+  `special` in use, before and after (several calls -- several threads over
+  disjoint pieces with side lists of their own, or one reader in turn -- fill
+  one batch); -2 if specialcapacity does not suffice.  Host code, no GPU.
+  A packed batch is a batch like any other to every engine call.  -complete,
+  -mum and -mum cand on an index with deep tables read the rows directly
+  (reads of up to 124 symbols); the other modes make the bytes on the device
+  first (once per batch: 0.3 ms per 10 M reads of 100 symbols).
+*/
+uint32_t vsa_packed_words(uint32_t querylength);
+int vsa_pack_reads(const uint8_t *symbols, uint64_t numofqueries,
+                   uint32_t querylength, uint64_t stride, uint64_t *rows,
+                   uint8_t *special, uint64_t specialcapacity,
+                   uint64_t *numofspecial);
+int vsa_queries_from_host_packed(const uint64_t *rows, uint64_t numofqueries,
+                                 uint32_t querylength, const uint8_t *special,
+                                 uint64_t numofspecial, int device,
+                                 vsa_queries **queries);
+
 /* vmatch -p: the batch with every sequence replaced by its reverse
    complement (symbol 3 - c, wildcards stay), what copymultiseqRC
    (kurtz-basic/readmulti.c:93-125) stores in Multiseq.rcsequence and the
@@ -572,6 +607,20 @@ int vsa_pipeline_open(const vsa_index *index, int mode, uint64_t searchlength,
                       vsa_pipeline **pipeline);
 uint8_t *vsa_pipeline_hostbuffer(vsa_pipeline *pipeline);
 int vsa_pipeline_submit(vsa_pipeline *pipeline, uint64_t numofqueries);
+/* The same pipeline for reads at two bits per symbol (vsa_pack_reads): a
+   quarter of the bytes cross PCIe and lie in HBM.  The caller packs into the
+   slot's page-locked room -- *rows: maxqueries rows of vsa_packed_words(m)
+   words, *special: maxspecial reads as bytes -- and submits the numbers it
+   used.  vsa_pipeline_hostrows: 0 = a slot, 1 = all three batches are in
+   flight (take results first).  Everything else as above. */
+int vsa_pipeline_open_packed(const vsa_index *index, int mode,
+                             uint64_t searchlength, uint32_t querylength,
+                             uint64_t maxqueries, uint64_t maxspecial,
+                             vsa_pipeline **pipeline);
+int vsa_pipeline_hostrows(vsa_pipeline *pipeline, uint64_t **rows,
+                          uint8_t **special);
+int vsa_pipeline_submit_packed(vsa_pipeline *pipeline, uint64_t numofqueries,
+                               uint64_t numofspecial);
 /* 0: the oldest batch not yet delivered (host memory, valid until the next
    call that needs its slot); 1: nothing outstanding; < 0: that batch failed
    (message in vsa_messagespace(), matches up to the error delivered) */

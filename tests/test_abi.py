@@ -69,6 +69,39 @@ def test_synthetic_generator_matches_recorded_md5(V):
     assert (V.lib.vsa_splitmix64_at(42, 999) >> 62) == g[999]
 
 
+def test_pack_reads_is_host_code_and_round_trips(V):
+    """vsa_pack_reads (no GPU): rows at two bits per symbol, first symbol in
+    the top bits, a flag byte; reads with a special symbol on the side list"""
+    rng = np.random.default_rng(3)
+    for m in (5, 28, 29, 32, 100, 124, 150):
+        nq = 200
+        sym = rng.integers(0, 4, nq * m).astype(np.uint8)
+        sym[7 * m + m // 2] = V.WILDCARD
+        sym[90 * m] = V.WILDCARD
+        rows, special, ns = V.pack_reads(sym, nq, m)
+        W = int(V.lib.vsa_packed_words(m))
+        assert W == (2 * m + 8 + 63) // 64 and ns == 2
+        r = rows.reshape(nq, W)
+        flagged = np.flatnonzero(r[:, W - 1] & np.uint64(0xFF))
+        assert list(flagged) == [7, 90]
+        assert np.array_equal(special[:m], sym[7 * m:8 * m])
+        assert int(r[90, 0]) == 1
+        for i in (0, 8, 199):
+            got = [(int(r[i, j // 32]) >> (62 - 2 * (j % 32))) & 3
+                   for j in range(m)]
+            assert got == list(sym[i * m:(i + 1) * m])
+            # nothing behind the last symbol but the flag byte
+            used = 2 * (m - 32 * (W - 1)) if m > 32 * (W - 1) else 0
+            assert int(r[i, W - 1]) & ((1 << (64 - used)) - 1) == 0
+    # the side list is too small: the reference-style error, nothing silent
+    rows = np.zeros(nq * W, np.uint64)
+    special = np.zeros(m, np.uint8)
+    ns = C.c_uint64(0)
+    rc = V.lib.vsa_pack_reads(V._ptr(sym), nq, m, m, V._ptr(rows),
+                              V._ptr(special), 1, C.byref(ns))
+    assert rc == -2 and "special symbol" in V.messagespace()
+
+
 def test_index_open_reports_reference_style_errors(V, tmp_path):
     with pytest.raises(V.VsaError) as e:
         V.Index.open(str(tmp_path / "nothing"))

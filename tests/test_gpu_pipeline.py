@@ -86,3 +86,56 @@ def test_slots_are_reused_and_errors_surface_per_batch(V):
     p.close()
     with pytest.raises(V.VsaError):
         V.Pipeline(gi, 7, 20, 100, 10)
+
+
+def run_packed_job(V, gi, sym, m, mode, L, per):
+    """the same job through a packed pipeline: the caller packs its reads
+    into the slot's page-locked rows (vsa_pack_reads)"""
+    nq = len(sym) // m
+    p = V.Pipeline(gi, mode, L, m, per, packed=True)
+    out, first = [], 0
+    while first < nq:
+        n = min(per, nq - first)
+        while not p.pack_into_slot(sym[first * m:(first + n) * m], n):
+            rc, got = p.next()             # all slots in flight: take one
+            assert rc == 0
+            out.append(got)
+        first += n
+    while True:
+        rc, got = p.next()
+        if rc == 1:
+            break
+        assert rc == 0
+        out.append(got)
+    res = np.concatenate(out) if out else np.zeros(0, V.MATCH_DTYPE)
+    if mode == 3:
+        res, st = p.finish()
+        assert st.count == len(res)
+    p.close()
+    return res
+
+
+@pytest.mark.parametrize("per", [10000, 999])
+def test_packed_pipeline_gives_the_reference_lists(V, per):
+    idx, q = H.load_case("c1")
+    gi = gpu_index(V, "c1")
+    gi.set_queryspeedup(2)
+    m = int(q.length[0])
+    for mode, key, L in ((0, "complete", 0), (2, "mumcand20", 20),
+                         (3, "mum20", 20), (1, "mem20_sp2", 20)):
+        got = run_packed_job(V, gi, q.symbols, m, mode, L, per)
+        assert np.array_equal(H.matches_as_ref(idx, got),
+                              H.expected("c1", key)), (per, key)
+    # reads with wildcards: the side list of every slot, batch after batch
+    sym = q.symbols.copy()
+    rng = np.random.default_rng(9)
+    hit = rng.integers(0, len(sym), 400)
+    sym[hit] = H.WILDCARD
+    hq = H.Queries.uniform(sym, m)
+    for mode, kw in ((2, dict(mum=True, cand=True)), (3, dict(mum=True)),
+                     (1, dict())):
+        got = run_packed_job(V, gi, sym, m, mode, 20, 2500)
+        want = H.oracle_querymatches(idx, hq, 20, speedup=2, **kw)
+        assert np.array_equal(got, want), mode
+    assert np.array_equal(run_packed_job(V, gi, sym, m, 0, 0, 2500),
+                          H.oracle_complete(idx, hq))

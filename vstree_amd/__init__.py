@@ -129,6 +129,9 @@ def _load():
         "vsa_index_clone": (I, [V, I, PP]),
         "vsa_pipeline_open": (I, [V, I, U64, U32, U64, PP]),
         "vsa_pipeline_hostbuffer": (V, [V]),
+        "vsa_pipeline_open_packed": (I, [V, I, U64, U32, U64, U64, PP]),
+        "vsa_pipeline_hostrows": (I, [V, PP, PP]),
+        "vsa_pipeline_submit_packed": (I, [V, U64, U64]),
         "vsa_pipeline_submit": (I, [V, U64]),
         "vsa_pipeline_next": (I, [V, PP, C.POINTER(U64)]),
         "vsa_pipeline_finish": (I, [V, PP, C.POINTER(U64),
@@ -138,6 +141,9 @@ def _load():
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),
         "vsa_queries_from_device": (I, [V, U64, U32, I, PP]),
+        "vsa_packed_words": (U32, [U32]),
+        "vsa_pack_reads": (I, [V, U64, U32, U64, V, V, U64, C.POINTER(U64)]),
+        "vsa_queries_from_host_packed": (I, [V, U64, U32, V, U64, I, PP]),
         "vsa_queries_reverse_complement": (I, [V, PP]),
         "vsa_queries_free": (None, [V]),
         "vsa_queries_set_offset": (I, [V, U64]),
@@ -337,6 +343,19 @@ class Queries:
                                          _ptr(start), _ptr(length),
                                          start.shape[0], device, C.byref(h)))
         return cls(h, start.shape[0])
+
+    @classmethod
+    def from_host_packed(cls, symbols, m, device=0, stride=None):
+        """nq reads of m mapped symbols (read i at symbols[i * stride:]) ->
+        packed on the host (vsa_pack_reads), uploaded as rows + side list"""
+        symbols = np.ascontiguousarray(symbols, np.uint8)
+        stride = m if stride is None else stride
+        nq = 0 if len(symbols) < m else (len(symbols) - m) // stride + 1
+        rows, special, ns = pack_reads(symbols, nq, m, stride)
+        h = C.c_void_p()
+        _check(lib.vsa_queries_from_host_packed(
+            _ptr(rows), nq, m, _ptr(special), ns, device, C.byref(h)))
+        return cls(h, nq)
 
     @classmethod
     def from_device(cls, device_symbols, nq, m, device=0):
@@ -639,14 +658,56 @@ class Pipeline:
     """vsa_pipeline_*: host memory in, host memory out, three batches in
     flight.  mode: 0 -complete, 1 MEM, 2 -mum cand, 3 -mum."""
 
-    def __init__(self, index, mode, searchlength, querylength, maxqueries):
+    def __init__(self, index, mode, searchlength, querylength, maxqueries,
+                 packed=False, maxspecial=None):
         self._h = None
         h = C.c_void_p()
-        _check(lib.vsa_pipeline_open(index._h, int(mode), int(searchlength),
-                                     int(querylength), int(maxqueries),
-                                     C.byref(h)))
+        self.packed = bool(packed)
+        self.maxspecial = int(maxqueries if maxspecial is None
+                              else maxspecial)
+        if packed:
+            _check(lib.vsa_pipeline_open_packed(
+                index._h, int(mode), int(searchlength), int(querylength),
+                int(maxqueries), self.maxspecial, C.byref(h)))
+        else:
+            _check(lib.vsa_pipeline_open(index._h, int(mode),
+                                         int(searchlength), int(querylength),
+                                         int(maxqueries), C.byref(h)))
         self._h, self._index = h, index
         self.m, self.maxqueries = int(querylength), int(maxqueries)
+        self.W = int(lib.vsa_packed_words(self.m))
+
+    def hostrows(self):
+        """packed pipelines: (rows, special) numpy views of the page-locked
+        room of the next batch, or None when all batches are in flight"""
+        r, sp = C.c_void_p(), C.c_void_p()
+        rc = lib.vsa_pipeline_hostrows(self._h, C.byref(r), C.byref(sp))
+        if rc == 1:
+            return None
+        _check(rc)
+        rows = np.ctypeslib.as_array(
+            (C.c_uint64 * (self.W * self.maxqueries)).from_address(r.value))
+        special = np.ctypeslib.as_array(
+            (C.c_uint8 * max(1, self.m * self.maxspecial)).from_address(
+                sp.value))
+        return rows, special
+
+    def pack_into_slot(self, symbols, nq, stride=None):
+        """packs nq reads into the next slot and submits it; False when all
+        batches are in flight"""
+        got = self.hostrows()
+        if got is None:
+            return False
+        rows, special = got
+        ns = C.c_uint64(0)
+        symbols = np.ascontiguousarray(symbols, np.uint8)
+        _check(lib.vsa_pack_reads(_ptr(symbols), nq, self.m,
+                                  self.m if stride is None else stride,
+                                  _ptr(rows), _ptr(special), self.maxspecial,
+                                  C.byref(ns)))
+        _check(lib.vsa_pipeline_submit_packed(self._h, int(nq),
+                                              int(ns.value)))
+        return True
 
     def hostbuffer(self):
         """numpy view of the page-locked buffer of the next batch, or None
@@ -766,6 +827,19 @@ def synth_queries(genome, nq, m, seed=QUERY_SEED):
     lib.vsa_synth_queries(seed, _ptr(genome), genome.shape[0], nq, m,
                           _ptr(q), None)
     return q
+
+
+def pack_reads(symbols, nq, m, stride=None, specialcap=None):
+    """-> (rows u64[nq * W], special u8[ns * m], ns)"""
+    stride = m if stride is None else stride
+    W = int(lib.vsa_packed_words(m))
+    rows = np.zeros(nq * W, np.uint64)
+    cap = nq if specialcap is None else specialcap
+    special = np.zeros(max(cap, 1) * m, np.uint8)
+    ns = C.c_uint64(0)
+    _check(lib.vsa_pack_reads(_ptr(symbols), nq, m, stride, _ptr(rows),
+                              _ptr(special), cap, C.byref(ns)))
+    return rows, special[:ns.value * m], int(ns.value)
 
 
 def synth_query_plan(n, nq, m, seed=QUERY_SEED):

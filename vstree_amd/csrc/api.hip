@@ -791,6 +791,11 @@ extern "C" void vsa_queries_free(vsa_queries *q)
   (void) hipFree(q->symbols);
   (void) hipFree(q->start);
   (void) hipFree(q->length);
+  if (q->ownsrows)
+  {
+    (void) hipFree(q->rows);
+    (void) hipFree(q->side);
+  }
   delete q;
 }
 
@@ -994,6 +999,15 @@ extern "C" int vsa_queries_reverse_complement(const vsa_queries *q,
   {
     return -100;
   }
+  // (a packed batch: its bytes first; the reverse complement is a byte batch)
+  if (q->rows != nullptr)
+  {
+    if (vsa_queries_bytes(q, nullptr) != 0)
+    {
+      return -100;
+    }
+    VSA_HIP(hipStreamSynchronize(nullptr));
+  }
   vsa_queries *r = new vsa_queries;
   r->device = q->device;
   r->nq = q->nq;
@@ -1048,6 +1062,198 @@ extern "C" int vsa_queries_set_offset(vsa_queries *q, uint64_t offset)
     return -1;
   }
   q->seqoffset = offset;
+  return 0;
+}
+
+// ---- reads at two bits per symbol -------------------------------------------
+
+extern "C" uint32_t vsa_packed_words(uint32_t querylength)
+{
+  return vsa_rowwords(querylength);
+}
+
+// One row per read, see include/vstree_amd.h.  Host code: the caller's reader
+// runs it while it parses (several threads over disjoint reads).
+extern "C" int vsa_pack_reads(const uint8_t *symbols, uint64_t numofqueries,
+                              uint32_t querylength, uint64_t stride,
+                              uint64_t *rows, uint8_t *special,
+                              uint64_t specialcapacity,
+                              uint64_t *numofspecial)
+{
+  if ((numofqueries > 0 && (symbols == nullptr || rows == nullptr)) ||
+      numofspecial == nullptr || querylength == 0 ||
+      (specialcapacity > 0 && special == nullptr))
+  {
+    VSA_ERROR("vsa_pack_reads: bad argument");
+    return -1;
+  }
+  const uint32_t m = querylength, W = vsa_rowwords(m);
+  uint64_t ns = *numofspecial;
+  for (uint64_t i = 0; i < numofqueries; i++)
+  {
+    const uint8_t *r = symbols + i * stride;
+    uint64_t *row = rows + i * W;
+    uint8_t bad = 0;
+    for (uint32_t w = 0; w < W; w++)
+    {
+      uint64_t acc = 0;
+      const uint32_t lo = 32 * w, hi = lo + 32 < m ? lo + 32 : m;
+      for (uint32_t j = lo; j < hi; j++)
+      {
+        const uint8_t c = r[j];
+        bad |= c;
+        acc |= (uint64_t) (c & 3u) << (62 - 2 * (j - lo));
+      }
+      row[w] = acc;
+    }
+    if (bad > 3)
+    {
+      // a symbol that is no base (a wildcard; in a Multiseq also a
+      // separator would be): the read travels as bytes
+      if (ns >= specialcapacity)
+      {
+        VSA_ERROR("vsa_pack_reads: more than %lu reads with a special symbol",
+                  (unsigned long) specialcapacity);
+        return -2;
+      }
+      memcpy(special + ns * m, r, m);
+      for (uint32_t w = 0; w < W; w++)
+      {
+        row[w] = 0;
+      }
+      row[0] = ns++;
+      row[W - 1] |= 1u;
+    }
+  }
+  *numofspecial = ns;
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_unpack_rows(const uint64_t *__restrict__ rows, uint32_t W,
+              const uint8_t *__restrict__ side, uint64_t nside, uint64_t nq,
+              uint32_t m, uint8_t *__restrict__ out)
+{
+  // one wavefront per read, a lane per pair of symbols
+  const uint64_t q = (vsa_bid() * 256 + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (q >= nq)
+  {
+    return;
+  }
+  const uint64_t *row = rows + q * W;
+  const bool flagged = (row[W - 1] & 0xFFu) != 0 && nside > 0;
+  const uint64_t k = flagged ? (row[0] < nside ? row[0] : nside - 1) : 0;
+  const uint8_t *sym = flagged ? side + k * (uint64_t) m : nullptr;
+  for (uint32_t j = lane; j < m; j += 64)
+  {
+    out[q * m + j] = flagged
+                         ? sym[j]
+                         : (uint8_t) ((row[j >> 5] >> (62 - 2 * (j & 31u))) &
+                                      3u);
+  }
+}
+
+// bytes (and the start / length arrays) of a packed batch, on the device, for
+// the kernels that read bytes; made once per batch
+int vsa_queries_bytes(const vsa_queries *cq, hipStream_t stream)
+{
+  vsa_queries *q = const_cast<vsa_queries *>(cq);
+  if (q->rows == nullptr || (q->symbols != nullptr && q->bytesvalid))
+  {
+    return 0;
+  }
+  const uint32_t m = (uint32_t) q->maxlength;
+  if (q->symbols == nullptr)
+  {
+    // (a pipeline slot: room for its largest batch, kept from batch to batch)
+    const uint64_t room = std::max(q->nsymbols, q->bytescapacity);
+    VSA_HIP(vsa_hip_malloc((void **) &q->symbols, room + VSA_QUERY_BACKPAD));
+  }
+  VSA_HIP(hipMemsetAsync(q->symbols + q->nsymbols, 0xFF, VSA_QUERY_BACKPAD,
+                         stream));
+  if (q->start == nullptr)
+  {
+    const uint64_t most = std::max<uint64_t>(q->nq, q->bytescapacity / m);
+    VSA_HIP(vsa_hip_malloc((void **) &q->start, (most + 1) * 8));
+    VSA_HIP(vsa_hip_malloc((void **) &q->length, (most + 1) * 8));
+  }
+  if (q->nq > 0)
+  {
+    k_unpack_rows<<<vsa_grid((q->nq * 64 + 255) / 256), 256, 0, stream>>>(
+        q->rows, q->roww, q->side, q->nside, q->nq, m, q->symbols);
+    VSA_HIP(hipGetLastError());
+    k_uniform_starts<<<vsa_grid((q->nq + 255) / 256), 256, 0, stream>>>(
+        q->start, q->length, q->nq, m);
+    VSA_HIP(hipGetLastError());
+  }
+  q->bytesvalid = true;
+  return 0;
+}
+
+extern "C" int vsa_queries_from_host_packed(const uint64_t *rows,
+                                            uint64_t numofqueries,
+                                            uint32_t querylength,
+                                            const uint8_t *special,
+                                            uint64_t numofspecial, int device,
+                                            vsa_queries **queries)
+{
+  if (queries == nullptr || querylength == 0 ||
+      (numofqueries > 0 && rows == nullptr) ||
+      (numofspecial > 0 && special == nullptr))
+  {
+    VSA_ERROR("vsa_queries_from_host_packed: bad argument");
+    return -1;
+  }
+  *queries = nullptr;
+  const uint32_t m = querylength, W = vsa_rowwords(m);
+  // a flagged row must name a read of the side list: checked here, on the
+  // host, because the kernels follow the index without asking
+  for (uint64_t i = 0; i < numofqueries; i++)
+  {
+    const uint64_t *row = rows + i * W;
+    if ((row[W - 1] & 0xFFu) != 0 && row[0] >= numofspecial)
+    {
+      VSA_ERROR("vsa_queries_from_host_packed: read %lu names entry %lu of a "
+                "side list of %lu reads", (unsigned long) i,
+                (unsigned long) row[0], (unsigned long) numofspecial);
+      return -2;
+    }
+  }
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  vsa_queries *q = new vsa_queries;
+  q->device = device;
+  q->nq = numofqueries;
+  q->nsymbols = numofqueries * (uint64_t) m;
+  q->seqoffset = 0;
+  q->symbols = nullptr;
+  q->start = q->length = nullptr;
+  q->hlength.assign(1, (uint64_t) m); // uniform batches never look at it
+  q->minlength = q->maxlength = numofqueries > 0 ? m : 0;
+  q->uniform = q->dense = numofqueries > 0;
+  q->roww = W;
+  q->nside = numofspecial;
+  *queries = q;
+  // (32 bytes of slack: the kernels read a row as two 16-byte loads)
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->rows,
+                                      numofqueries * W * 8 + 64));
+  VSA_HIPQ(q, queries, vsa_hip_malloc((void **) &q->side,
+                                      numofspecial * (uint64_t) m + 64));
+  if (numofqueries > 0)
+  {
+    VSA_HIPQ(q, queries, hipMemcpy(q->rows, rows, numofqueries * W * 8,
+                                   hipMemcpyHostToDevice));
+  }
+  VSA_HIPQ(q, queries, hipMemset(q->rows + numofqueries * W, 0, 64));
+  if (numofspecial > 0)
+  {
+    VSA_HIPQ(q, queries, hipMemcpy(q->side, special,
+                                   numofspecial * (uint64_t) m,
+                                   hipMemcpyHostToDevice));
+  }
   return 0;
 }
 

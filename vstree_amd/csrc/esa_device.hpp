@@ -58,6 +58,86 @@ __device__ __forceinline__ vsa_u128 vsa_load16(const void *p)
   return v;
 }
 
+// ---- reads that live in HBM at two bits per symbol (DevQueries::rows) ------
+// The fast paths take such a read as a PackedQuery (registers); the paths that
+// compare byte for byte -- the reference walk, a comparison that met a special
+// symbol of the text -- see it through a QSrc, a "pointer to symbols" that
+// expands eight of them from the row when asked.  A read with a special symbol
+// of its own has its bytes in the batch's side buffer (`bytes` != nullptr) and
+// is read from there.  Positions behind the read hold 0xFF, like the padding
+// behind a byte batch.
+struct QSrc
+{
+  const uint64_t *row;  // the read's words, symbol 0 in the top bits of row[0]
+  const uint8_t *bytes; // or its symbols as bytes (reads with a wildcard)
+  int32_t pos;          // the symbol this "pointer" stands at
+  int32_t m;            // symbols of the read
+
+  __device__ __forceinline__ QSrc operator+(uint32_t k) const
+  {
+    QSrc q = *this;
+    q.pos += (int32_t) k;
+    return q;
+  }
+};
+
+// symbols [at, at + 32) of a row of `words` words, zeros behind them
+__device__ __forceinline__ uint64_t vsa_row_window(const uint64_t *row,
+                                                   uint32_t at)
+{
+  // (rows lie back to back and the batch has a word of slack behind it: the
+  // word behind the one that holds `at` can always be read)
+  const uint32_t i = at >> 5, sh = 2u * (at & 31u);
+  const uint64_t a = row[i], b = row[i + 1];
+  return sh != 0 ? (a << sh) | (b >> (64 - sh)) : a;
+}
+
+// eight symbols from q.pos on, one byte each, the first in the lowest byte
+__device__ __forceinline__ uint64_t vsa_load8(const QSrc &q)
+{
+  const int32_t rem = q.m - q.pos;
+  if (rem <= 0)
+  {
+    return ~0ull;
+  }
+  uint64_t r;
+  if (q.bytes != nullptr)
+  {
+    __builtin_memcpy(&r, q.bytes + q.pos, 8);
+  } else
+  {
+    const uint32_t v = (uint32_t) (vsa_row_window(q.row, (uint32_t) q.pos) >> 48);
+    r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+      r |= (uint64_t) ((v >> (14 - 2 * k)) & 3u) << (8 * k);
+    }
+  }
+  if (rem < 8)
+  {
+    r |= ~0ull << (8 * rem);
+  }
+  return r;
+}
+
+__device__ __forceinline__ vsa_u128 vsa_load16(const QSrc &q)
+{
+  vsa_u128 v;
+  v.lo = vsa_load8(q);
+  v.hi = vsa_load8(q + 8u);
+  return v;
+}
+
+__device__ __forceinline__ uint8_t vsa_qsym(const QSrc &q, uint32_t i)
+{
+  return (uint8_t) (vsa_load8(q + i) & 0xFFu);
+}
+__device__ __forceinline__ uint8_t vsa_qsym(const uint8_t *q, uint32_t i)
+{
+  return q[i];
+}
+
 // 0x80 in every byte of v that is a special symbol (>= 254)
 __device__ __forceinline__ uint64_t vsa_specialmask(uint64_t v)
 {
@@ -70,10 +150,9 @@ __device__ __forceinline__ uint64_t vsa_specialmask(uint64_t v)
 // of the reference's retcode (0 query exhausted, <0 query smaller or suffix
 // hit a special symbol / the end of the text, >0 query larger) and leaves the
 // matched length in lcplen.  Positions >= n of the device text hold 0xFF.
-template <typename IDX>
+template <typename IDX, typename QP = const uint8_t *>
 __device__ __forceinline__ int vsa_compare(const DevIndex<IDX> &ix,
-                                           uint64_t sufstart,
-                                           const uint8_t *query,
+                                           uint64_t sufstart, QP query,
                                            uint32_t querylen,
                                            uint32_t &lcplen)
 {
@@ -115,10 +194,9 @@ __device__ __forceinline__ int vsa_compare(const DevIndex<IDX> &ix,
 // usually stop within the first piece; the first pass of a MUM batch, where
 // most reads match over their whole length, asks for 3 so that a 100 bp read
 // is compared in one round trip instead of three.
-template <typename IDX, int AHEAD = 1>
+template <typename IDX, int AHEAD = 1, typename QP = const uint8_t *>
 __device__ __forceinline__ int vsa_compare32(const DevIndex<IDX> &ix,
-                                             uint64_t sufstart,
-                                             const uint8_t *query,
+                                             uint64_t sufstart, QP query,
                                              uint32_t querylen,
                                              uint32_t &lcplen)
 {
@@ -425,6 +503,81 @@ __device__ __forceinline__ void vsa_pq_stage(const DevQueries &qs, uint64_t q0,
   }
 }
 
+// Read q of a packed batch (DevQueries::rows, reads of m <= 124 symbols: at
+// most four words): its symbols into pq -- two 16-byte loads, neighbouring
+// lanes on neighbouring rows --, and the QSrc the byte paths look through.
+// A read with a special symbol (flag byte 1) has its bytes in the side buffer
+// at the index its word 0 names; it is packed from there, up to the symbol.
+__device__ __forceinline__ void vsa_pq_from_row(const DevQueries &qs,
+                                                uint64_t q, uint32_t m,
+                                                PackedQuery &pq, QSrc &src)
+{
+  const uint32_t W = qs.roww;
+  const uint64_t *row = qs.rows + q * W;
+  // (32 bytes whatever W is: the batch has that much slack behind it)
+  const vsa_u128 a = vsa_load16(row), b = vsa_load16(row + 2);
+  const uint64_t last = W == 1 ? a.lo : (W == 2 ? a.hi : (W == 3 ? b.lo : b.hi));
+  pq.w[0] = a.lo;
+  pq.w[1] = W > 1 ? a.hi : 0;
+  pq.w[2] = W > 2 ? b.lo : 0;
+  pq.w[3] = W > 3 ? b.hi : 0;
+  // the flag byte is no symbol
+  if (W == 1)
+  {
+    pq.w[0] &= ~0xFFull;
+  } else if (W == 2)
+  {
+    pq.w[1] &= ~0xFFull;
+  } else if (W == 3)
+  {
+    pq.w[2] &= ~0xFFull;
+  } else
+  {
+    pq.w[3] &= ~0xFFull;
+  }
+  pq.valid = m;
+  src.row = row;
+  src.bytes = nullptr;
+  src.pos = 0;
+  src.m = (int32_t) m;
+  if ((last & 0xFFu) != 0 && qs.nside > 0)
+  {
+    // (the index is clamped to the list: a row that lies reads another read,
+    // never another buffer)
+    const uint64_t k = a.lo < qs.nside ? a.lo : qs.nside - 1;
+    const uint8_t *sym = qs.side + k * (uint64_t) m;
+    uint32_t firstbad = m;
+    src.bytes = sym;
+#pragma unroll
+    for (int wi = 0; wi < 4; wi++)
+    {
+      uint64_t acc = 0;
+      for (uint32_t k = 0; k < 32; k++)
+      {
+        const uint32_t j = 32u * (uint32_t) wi + k;
+        if (j < m)
+        {
+          const uint8_t c = sym[j];
+          if (c > 3 && firstbad == m)
+          {
+            firstbad = j;
+          }
+          acc |= (uint64_t) (c & 3u) << (62 - 2 * k);
+        }
+      }
+      pq.w[wi] = acc;
+    }
+    pq.valid = firstbad;
+  }
+}
+
+// symbol i of a packed query (i < 128)
+__device__ __forceinline__ uint8_t vsa_pq_symbol(const PackedQuery &pq,
+                                                 uint32_t i)
+{
+  return (uint8_t) (vsa_pq_window(pq, i) >> 62);
+}
+
 // vsa_extend_packed for a query that is in registers already
 template <int CHUNKS, typename IDX, typename QT>
 __device__ __forceinline__ bool
@@ -564,10 +717,10 @@ __device__ __forceinline__ uint32_t vsa_lcpbyte(const DevIndex<IDX> &ix,
 // binary search over suf[vleft..vright]; all suffixes there share `offset`
 // symbols with the query.  The probe sequence is the reference's, so the
 // witness is the reference's witness.
-template <typename IDX>
+template <typename IDX, typename QP = const uint8_t *>
 __device__ __forceinline__ void
 vsa_findmaxprefixlen(const DevIndex<IDX> &ix, uint64_t vleft, uint64_t vright,
-                     uint32_t offset, const uint8_t *query, uint32_t querylen,
+                     uint32_t offset, QP query, uint32_t querylen,
                      uint32_t &maxlcp, uint64_t &witness)
 {
   uint32_t lcplen = offset, lpref, rpref;
@@ -703,10 +856,9 @@ __device__ __forceinline__ uint64_t vsa_evallcp(const DevIndex<IDX> &ix,
 }
 
 // include/qgram2code.c:7-37
-template <typename IDX>
+template <typename IDX, typename QP = const uint8_t *>
 __device__ __forceinline__ bool vsa_qgram2code(const DevIndex<IDX> &ix,
-                                               const uint8_t *qgram,
-                                               uint64_t &code)
+                                               QP qgram, uint64_t &code)
 {
   uint64_t c = 0;
   bool ok = true;
@@ -715,7 +867,7 @@ __device__ __forceinline__ bool vsa_qgram2code(const DevIndex<IDX> &ix,
   {
     for (uint32_t i = 0; i < ix.pl; i++)
     {
-      const uint8_t a = qgram[i];
+      const uint8_t a = vsa_qsym(qgram, i);
       ok = ok && !VSA_ISSPECIAL(a);
       c = (c << 2) | (a & 3);
     }
@@ -723,7 +875,7 @@ __device__ __forceinline__ bool vsa_qgram2code(const DevIndex<IDX> &ix,
   {
     for (uint32_t i = 0; i < ix.pl; i++)
     {
-      const uint8_t a = qgram[i];
+      const uint8_t a = vsa_qsym(qgram, i);
       ok = ok && !VSA_ISSPECIAL(a);
       c = c * ix.numofchars + a;
     }
@@ -735,9 +887,8 @@ __device__ __forceinline__ bool vsa_qgram2code(const DevIndex<IDX> &ix,
 // bucket of the first prefixlength symbols: Vmengine/exactcompl.c:186-194 /
 // kurtz/matchsub.c:199-205.  false: q-gram has a special symbol or the
 // bucket holds no suffix.
-template <typename IDX>
-__device__ __forceinline__ bool vsa_bucket(const DevIndex<IDX> &ix,
-                                           const uint8_t *qgram,
+template <typename IDX, typename QP = const uint8_t *>
+__device__ __forceinline__ bool vsa_bucket(const DevIndex<IDX> &ix, QP qgram,
                                            uint64_t &vleft, uint64_t &vright)
 {
   uint64_t code;
@@ -758,10 +909,10 @@ __device__ __forceinline__ bool vsa_bucket(const DevIndex<IDX> &ix,
 }
 
 // the reference's way to a (maxlcp, witness) pair
-template <typename IDX>
+template <typename IDX, typename QP = const uint8_t *>
 __device__ __forceinline__ bool
-vsa_locate_reference(const DevIndex<IDX> &ix, const uint8_t *query,
-                     uint32_t querylen, uint32_t &maxlcp, uint64_t &witness)
+vsa_locate_reference(const DevIndex<IDX> &ix, QP query, uint32_t querylen,
+                     uint32_t &maxlcp, uint64_t &witness)
 {
   uint64_t vleft, vright;
 
@@ -841,9 +992,10 @@ struct DeepFront
   int state;                 // VSA_LOC_NONE / FOUND (= go on) / SLOW
 };
 
-template <bool PQ = false, typename IDX = uint32_t, typename QT = PackedQuery>
+template <bool PQ = false, typename IDX = uint32_t, typename QT = PackedQuery,
+          typename QP = const uint8_t *>
 __device__ __forceinline__ void
-vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
+vsa_deep_front(const DevIndex<IDX> &ix, bool active, QP query,
                uint32_t querylen, DeepFront &f,
                const QT *pq = nullptr, uint32_t pqoff = 0)
 {
@@ -864,7 +1016,7 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
     } else
     {
       // 32 query symbols as four 8-byte words (the buffer is padded)
-      const vsa_u128 qlo = vsa_load16(query), qhi = vsa_load16(query + 16);
+      const vsa_u128 qlo = vsa_load16(query), qhi = vsa_load16(query + 16u);
       const uint64_t w0 = qlo.lo, w1 = qlo.hi, w2 = qhi.lo, w3 = qhi.hi;
       // this path exists for the DNA alphabet only (symbols 0..3): every
       // other byte -- wildcard, separator -- ends the regular prefix
@@ -925,9 +1077,10 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, const uint8_t *query,
 // matches); lanes whose comparison met a special symbol of the text repeat it
 // on the bytes.  PQ: the query is *pq (symbols from pqoff on), `query` its
 // bytes for the fallback.
-template <int AHEAD, bool PQ, typename IDX, typename QT>
+template <int AHEAD, bool PQ, typename IDX, typename QT,
+          typename QP = const uint8_t *>
 __device__ __forceinline__ void
-vsa_extend_tie(const DevIndex<IDX> &ix, uint64_t sstart, const uint8_t *query,
+vsa_extend_tie(const DevIndex<IDX> &ix, uint64_t sstart, QP query,
                uint32_t querylen, uint32_t &maxlcp, const QT *pq,
                uint32_t pqoff)
 {
@@ -955,10 +1108,10 @@ vsa_extend_tie(const DevIndex<IDX> &ix, uint64_t sstart, const uint8_t *query,
 
 // the deep locate from a front that is at hand (all lanes, see below)
 template <int AHEAD = 1, bool PQ = false, typename IDX = uint32_t,
-          typename QT = PackedQuery>
+          typename QT = PackedQuery, typename QP = const uint8_t *>
 __device__ __forceinline__ int
-vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
-                     const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
+vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f, QP query,
+                     uint32_t querylen, uint32_t &maxlcp,
                      uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
                      uint32_t qleft = 0x100u, const QT *pq = nullptr,
                      uint32_t pqoff = 0)
@@ -1194,10 +1347,10 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f,
 }
 
 template <int AHEAD = 1, bool PQ = false, typename IDX = uint32_t,
-          typename QT = PackedQuery>
+          typename QT = PackedQuery, typename QP = const uint8_t *>
 __device__ __forceinline__ int
-vsa_locate_deep(const DevIndex<IDX> &ix, bool active,
-                const uint8_t *query, uint32_t querylen, uint32_t &maxlcp,
+vsa_locate_deep(const DevIndex<IDX> &ix, bool active, QP query,
+                uint32_t querylen, uint32_t &maxlcp,
                 uint64_t &w, DeepHit &hit, uint32_t needleft = 0xFFFFFFFFu,
                 uint32_t qleft = 0x100u, const QT *pq = nullptr,
                 uint32_t pqoff = 0)

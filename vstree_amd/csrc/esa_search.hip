@@ -410,6 +410,15 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   vsa_dev_set_stream(stream);
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
+  // packed batches: read from their rows by the deep kernel; an index
+  // without deep tables (or reads beyond four words) takes their bytes
+  const bool rows = queries->rows != nullptr && ix.esa8 != nullptr &&
+                    queries->roww <= 4 && queries->maxlength >= ix.D;
+  if (queries->rows != nullptr && !rows &&
+      vsa_queries_bytes(queries, stream) != 0)
+  {
+    return -100;
+  }
   const DevQueries qs = devqueries(queries);
   DevBuf left, count, offsets, temp, matches;
   uint64_t total = 0;
@@ -429,9 +438,14 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   tsearch.start();
   {
     const bool staged = ix.esa8 != nullptr && qs.dense != 0 &&
-                        qs.uniformlen <= 128 && (qs.uniformlen & 3u) == 0 &&
-                        qs.uniformlen >= ix.D;
-    if (staged)
+                        qs.symbols != nullptr && qs.uniformlen <= 128 &&
+                        (qs.uniformlen & 3u) == 0 && qs.uniformlen >= ix.D;
+    if (rows)
+    {
+      k_complete_search<IDX, true, true, true>
+          <<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+              ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+    } else if (staged)
     {
       k_complete_search<IDX, true, true>
           <<<gridfor(qlimit), VSA_BLOCK, (size_t) VSA_BLOCK * qs.uniformlen,
@@ -952,7 +966,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   vsa_dev_set_stream(stream);
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
-  const DevQueries qs = devqueries(queries);
+  DevQueries qs = devqueries(queries);
   DevBuf base, cursor, out, keys;
   uint64_t nitems = 0;
   uint32_t perquery = 0;
@@ -1073,9 +1087,23 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // lcptab rules out (see vsa_index::lcpquirk).  A plan holds 16-bit offsets.
   // VSA_TUNE=2: no work reduction (every offset is searched by the list form
   // of the search kernel -- the cross-check of everything below).
-  if (domum && maxoffsets > 1 && maxoffsets < 0xFFFFu &&
-      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0 &&
-      !(queries->maxlength >= 255 && index->lcpquirk != 0))
+  const bool reduce = domum && maxoffsets > 1 && maxoffsets < 0xFFFFu &&
+                      queries->nq < 0xFFFFFFFFull && (index->tune & 2u) == 0 &&
+                      !(queries->maxlength >= 255 && index->lcpquirk != 0);
+  // packed batches (reads at two bits per symbol): first pass, plan and
+  // search kernel read the rows; everything else takes the bytes, which are
+  // made on the device once per batch
+  const bool rows = queries->rows != nullptr && reduce && deepok &&
+                    queries->roww <= 4;
+  if (queries->rows != nullptr && !rows)
+  {
+    if (vsa_queries_bytes(queries, stream) != 0)
+    {
+      return -100;
+    }
+    qs = devqueries(queries);
+  }
+  if (reduce)
   {
     const uint64_t nq = queries->nq;
     if (wcount.alloc((nq + 1) * 4) || wfirste.alloc(nq * 4) ||
@@ -1086,7 +1114,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
     tfirst.start();
-    if (deepok)
+    if (rows)
+    {
+      k_mum_first<IDX, true, true, true>
+          <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+              ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+              wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+              wfmdb.as<uint64_t>());
+    } else if (deepok)
     {
       // reads of one length m (a multiple of 4, <= 128), back to back:
       // staged through LDS and packed
@@ -1190,10 +1225,21 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         em.cursors = pcursor.as<unsigned long long>();
         em.packbits = packbits;
         em.valbits = valbits;
-        k_mum_plan<IDX, true, true><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-            ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
-            wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
-            wplan.as<PlanRanges>(), em);
+        if (rows)
+        {
+          k_mum_plan<IDX, true, true, true>
+              <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+                  ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+                  wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
+                  wplan.as<PlanRanges>(), em);
+        } else
+        {
+          k_mum_plan<IDX, true, true>
+              <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
+                  ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+                  wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
+                  wplan.as<PlanRanges>(), em);
+        }
         k_shard_summary<<<1, 1024, 0, stream>>>(
             pcursor.as<unsigned long long>(), nshards, pdoff.as<uint64_t>(),
             nullptr, nullptr, psummary.as<uint64_t>());
@@ -1283,7 +1329,16 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           ix, qs, dbase, perquery, nwork, searchlength,                       \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
-    if (fromplan && deepok)
+    if (fromplan && rows)
+    {
+      k_query_search_planned<IDX, 256, true, true>
+          <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
+              ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+              wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
+              rawkeys.as<uint64_t>(), shardcap, nshards - 1,
+              cursor.as<unsigned long long>(), packbits, valbits,
+              blocksum.as<unsigned long long>());
+    } else if (fromplan && deepok)
     {
       k_query_search_planned<IDX, 256, true>
           <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
@@ -1520,14 +1575,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
 // ---- K3 pipeline ----
 
 // workgroups of the streaming pass: 4 per CU = all the wavefronts that fit
-// with 100 VGPRs each, every one walking its tiles grid-stride
-// (VSA_PEAKBLOCKS overrides, for experiments)
-static uint64_t vsa_peakblocks(void)
-{
-  const char *e = getenv("VSA_PEAKBLOCKS");
-  const long v = (e != NULL) ? atol(e) : 0;
-  return v > 0 ? (uint64_t) v : 0;
-}
+// (86 registers, four per SIMD), every one walking its tiles grid-stride
+#define VSA_PEAK_BLOCKS 1024
 
 // [first, last) = the values of the reference's loop variable i
 // (fmumself.c:33: i = 2 .. n-1) this call covers
@@ -1541,10 +1590,6 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   const DevIndex<IDX> ix = index->view<IDX>();
   const uint64_t n = index->n;
   const uint32_t nshards = VSA_CURSOR_SHARDS;
-  // VSA_PEAK_ROLLING=W (experiment of round 4): the one-tile kernel at W
-  // wavefronts per SIMD; 0: the two-tile kernel of round 3
-  const char *rollenv = getenv("VSA_PEAK_ROLLING");
-  const int rolling = rollenv != nullptr ? atoi(rollenv) : 0;
   const uint64_t pieces = 4, tilesize = 64 * pieces * 16;
   // centres j = i - 1
   const uint64_t jlo = std::max<uint64_t>(first, 2) - 1,
@@ -1555,10 +1600,7 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
   const uint64_t nblocks = std::max<uint64_t>(
       1, std::min<uint64_t>((ntiles - tile0 + wavesperblock - 1) /
                                 wavesperblock,
-                            vsa_peakblocks() != 0
-                                ? vsa_peakblocks()
-                                : (uint64_t) 256 * (rolling > 0 ? rolling
-                                                                : 4)));
+                            (uint64_t) VSA_PEAK_BLOCKS));
   const uint32_t slmin = (uint32_t) (searchlength < 255 ? searchlength : 255);
   DevBuf cursor, doff, rawpos, peaks, sorted, temp, cand, keep, dcount, mums;
   uint64_t shardcap =
@@ -1585,26 +1627,10 @@ int run_selfmum(const vsa_index *index, uint64_t searchlength,
     VSA_HIP(hipMemsetAsync(cursor.p, 0,
                            (size_t) nshards * VSA_CURSOR_STRIDE * 8, stream));
     tsearch.start();
-#define VSA_PEAKS(PIECES, NT)                                                 \
-  k_selfmum_peaks<PIECES, NT, IDX><<<(unsigned int) nblocks, VSA_BLOCK, 0,    \
-                                     stream>>>(                               \
-      ix.lcp, ix.bwt, n, slmin, rawpos.as<IDX>(), shardcap, nshards - 1,      \
-      cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi)
-#define VSA_PEAKS_ROLLING(WAVES)                                              \
-  k_selfmum_peaks_rolling<true, IDX, WAVES>                                   \
-      <<<(unsigned int) nblocks, VSA_BLOCK, 0, stream>>>(                     \
-          ix.lcp, ix.bwt, n, slmin, rawpos.as<IDX>(), shardcap, nshards - 1,  \
-          cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi)
-    switch (rolling)
-    {
-      case 4: VSA_PEAKS_ROLLING(4); break;
-      case 5: VSA_PEAKS_ROLLING(5); break;
-      case 6: VSA_PEAKS_ROLLING(6); break;
-      case 8: VSA_PEAKS_ROLLING(8); break;
-      default: VSA_PEAKS(4, true); break;
-    }
-#undef VSA_PEAKS_ROLLING
-#undef VSA_PEAKS
+    k_selfmum_peaks<true, IDX><<<(unsigned int) nblocks, VSA_BLOCK, 0,
+                                 stream>>>(
+        ix.lcp, ix.bwt, n, slmin, rawpos.as<IDX>(), shardcap, nshards - 1,
+        cursor.as<unsigned long long>(), tile0, ntiles, jlo, jhi);
     tsearch.stop();
     VSA_HIP(hipGetLastError());
     k_shard_summary<<<1, 1024, 0, stream>>>(
@@ -3140,6 +3166,15 @@ extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
     VSA_ERROR("queries live on device %d, index on device %d",
               queries->device, index->device);
     return -1;
+  }
+  if (queries->rows != nullptr)
+  {
+    // a packed batch: the approximate kernels read bytes
+    if (vsa_set_device(index->device) != 0 ||
+        vsa_queries_bytes(queries, index->stream) != 0)
+    {
+      return -100;
+    }
   }
   if (percent != 0 && index->bck != nullptr && index->numofchars == 4 &&
       (queries->minlength * distvalue) / 100 == 0 &&

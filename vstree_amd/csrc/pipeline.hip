@@ -53,6 +53,11 @@ enum SlotState
 struct Slot
 {
   SlotState state = SLOT_FREE;
+  // packed pipelines: rows (maxqueries * W words) and the side list
+  // (maxspecial * m bytes) instead of hostq, page-locked
+  uint64_t *hostrows = nullptr;
+  uint8_t *hostside = nullptr;
+  uint64_t nside = 0;
   uint8_t *hostq = nullptr;   // page-locked, maxqueries * m
   vsa_match *hostm = nullptr; // page-locked, grown on demand
   uint64_t hostmcap = 0;
@@ -72,6 +77,9 @@ struct vsa_pipeline
   int mode = 0;
   uint64_t searchlength = 0, maxqueries = 0, submitted = 0;
   uint32_t m = 0, lengthbits = 0;
+  bool packed = false; // reads at two bits per symbol (vsa_pipeline_open_packed)
+  uint32_t roww = 0;
+  uint64_t maxspecial = 0;
   Slot slot[kSlots];
   hipStream_t up = nullptr, down = nullptr;
   std::mutex lock;
@@ -174,6 +182,8 @@ void work(vsa_pipeline *p)
       s.q->nq = s.nq;
       s.q->nsymbols = s.nq * (uint64_t) p->m;
       s.q->seqoffset = s.first;
+      s.q->nside = s.nside;
+      s.q->bytesvalid = false; // (packed: the slot holds another batch now)
       switch (p->mode)
       {
         case 0: rc = vsa_findcompletematches(p->index, s.q, &res); break;
@@ -257,9 +267,37 @@ void releaseslot(vsa_pipeline *p, int k)
 
 } // namespace
 
+namespace
+{
+int pipeline_open(const vsa_index *index, int mode, uint64_t searchlength,
+                  uint32_t querylength, uint64_t maxqueries, bool packed,
+                  uint64_t maxspecial, vsa_pipeline **pipeline);
+}
+
 extern "C" int vsa_pipeline_open(const vsa_index *index, int mode,
                                  uint64_t searchlength, uint32_t querylength,
                                  uint64_t maxqueries, vsa_pipeline **pipeline)
+{
+  return pipeline_open(index, mode, searchlength, querylength, maxqueries,
+                       false, 0, pipeline);
+}
+
+extern "C" int vsa_pipeline_open_packed(const vsa_index *index, int mode,
+                                        uint64_t searchlength,
+                                        uint32_t querylength,
+                                        uint64_t maxqueries,
+                                        uint64_t maxspecial,
+                                        vsa_pipeline **pipeline)
+{
+  return pipeline_open(index, mode, searchlength, querylength, maxqueries,
+                       true, maxspecial, pipeline);
+}
+
+namespace
+{
+int pipeline_open(const vsa_index *index, int mode, uint64_t searchlength,
+                  uint32_t querylength, uint64_t maxqueries, bool packed,
+                  uint64_t maxspecial, vsa_pipeline **pipeline)
 {
   if (index == nullptr || pipeline == nullptr || mode < 0 || mode > 3 ||
       querylength == 0 || maxqueries == 0)
@@ -278,6 +316,9 @@ extern "C" int vsa_pipeline_open(const vsa_index *index, int mode,
   p->searchlength = searchlength;
   p->m = querylength;
   p->maxqueries = maxqueries;
+  p->packed = packed;
+  p->roww = vsa_rowwords(querylength);
+  p->maxspecial = maxspecial;
   while ((querylength >> p->lengthbits) != 0)
   {
     p->lengthbits++;
@@ -308,6 +349,28 @@ extern "C" int vsa_pipeline_open(const vsa_index *index, int mode,
     q->uniform = q->dense = true;
     q->hlength.assign(1, querylength); // uniform batches never look at it
     s.q = q;
+    if (packed)
+    {
+      // rows and side list in place of the symbols; the bytes (MEM mode) are
+      // made on the device when a batch needs them, into room kept here
+      const uint64_t rowbytes = maxqueries * p->roww * 8 + 64,
+                     sidebytes = maxspecial * (uint64_t) querylength + 64;
+      q->roww = p->roww;
+      q->bytescapacity = nsym;
+      ok = hipHostMalloc((void **) &s.hostrows, rowbytes,
+                         hipHostMallocDefault) == hipSuccess &&
+           hipHostMalloc((void **) &s.hostside, sidebytes,
+                         hipHostMallocDefault) == hipSuccess &&
+           vsa_hip_malloc((void **) &q->rows, rowbytes) == hipSuccess &&
+           vsa_hip_malloc((void **) &q->side, sidebytes) == hipSuccess &&
+           hipMemsetAsync(q->rows, 0, rowbytes, p->up) == hipSuccess &&
+           hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming) ==
+               hipSuccess &&
+           hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming) ==
+               hipSuccess &&
+           growhost(s, maxqueries + maxqueries / 2) == 0;
+      continue;
+    }
     ok = hipHostMalloc((void **) &s.hostq, nsym + VSA_QUERY_BACKPAD,
                        hipHostMallocDefault) == hipSuccess &&
          vsa_hip_malloc((void **) &q->symbols, nsym + VSA_QUERY_BACKPAD) ==
@@ -345,6 +408,7 @@ extern "C" int vsa_pipeline_open(const vsa_index *index, int mode,
   *pipeline = p;
   return 0;
 }
+} // namespace
 
 // The host buffer of the next batch: maxqueries * querylength bytes, symbols
 // of read i at [i * querylength, (i+1) * querylength).  NULL if all three
@@ -377,7 +441,61 @@ extern "C" uint8_t *vsa_pipeline_hostbuffer(vsa_pipeline *p)
   return p->filling >= 0 ? p->slot[p->filling].hostq : nullptr;
 }
 
+// The same for a packed pipeline: *rows = room for maxqueries rows of
+// vsa_packed_words(querylength) words, *special = room for maxspecial reads as
+// bytes (vsa_pack_reads fills both).  0: a slot is handed out; 1: all three
+// batches are in flight (take results with vsa_pipeline_next first).
+extern "C" int vsa_pipeline_hostrows(vsa_pipeline *p, uint64_t **rows,
+                                     uint8_t **special)
+{
+  if (p == nullptr || !p->packed || rows == nullptr || special == nullptr)
+  {
+    VSA_ERROR("vsa_pipeline_hostrows: bad argument (a packed pipeline?)");
+    return -1;
+  }
+  *rows = nullptr;
+  *special = nullptr;
+  (void) vsa_pipeline_hostbuffer(p); // picks the slot (hostq is null here)
+  std::lock_guard<std::mutex> g(p->lock);
+  if (p->filling < 0)
+  {
+    return 1;
+  }
+  *rows = p->slot[p->filling].hostrows;
+  *special = p->slot[p->filling].hostside;
+  return 0;
+}
+
+namespace
+{
+int pipeline_submit(vsa_pipeline *p, uint64_t nq, uint64_t nspecial);
+}
+
 extern "C" int vsa_pipeline_submit(vsa_pipeline *p, uint64_t nq)
+{
+  if (p == nullptr || p->packed)
+  {
+    VSA_ERROR("vsa_pipeline_submit: bad argument (a packed pipeline takes "
+              "vsa_pipeline_submit_packed)");
+    return -1;
+  }
+  return pipeline_submit(p, nq, 0);
+}
+
+extern "C" int vsa_pipeline_submit_packed(vsa_pipeline *p, uint64_t nq,
+                                          uint64_t nspecial)
+{
+  if (p == nullptr || !p->packed || nspecial > p->maxspecial)
+  {
+    VSA_ERROR("vsa_pipeline_submit_packed: bad argument");
+    return -1;
+  }
+  return pipeline_submit(p, nq, nspecial);
+}
+
+namespace
+{
+int pipeline_submit(vsa_pipeline *p, uint64_t nq, uint64_t nspecial)
 {
   if (p == nullptr || nq > p->maxqueries)
   {
@@ -398,18 +516,38 @@ extern "C" int vsa_pipeline_submit(vsa_pipeline *p, uint64_t nq)
   }
   Slot &s = p->slot[k];
   s.nq = nq;
+  s.nside = nspecial;
   s.first = p->submitted;
   const uint64_t nsym = nq * (uint64_t) p->m;
-  // what lies behind the last read must stop every comparison
-  memset(s.hostq + nsym, 0xFF, VSA_QUERY_BACKPAD);
   // (a batch that could not be queued leaves the pipeline as it was: the
   // buffer stays handed out, the numbering of the queries does not move)
   hipError_t e = vsa_set_device(p->index->device) != 0 ? hipErrorInvalidDevice
                                                        : hipSuccess;
-  if (e == hipSuccess)
+  if (p->packed)
   {
-    e = hipMemcpyAsync(s.q->symbols, s.hostq, nsym + VSA_QUERY_BACKPAD,
-                       hipMemcpyHostToDevice, p->up);
+    // (a flagged row names a read of the side list; the kernels clamp the
+    // index to the list, so a row that lies cannot make them read elsewhere)
+    const uint32_t W = p->roww;
+    memset(s.hostrows + nq * W, 0, 32);
+    if (e == hipSuccess)
+    {
+      e = hipMemcpyAsync(s.q->rows, s.hostrows, nq * W * 8 + 32,
+                         hipMemcpyHostToDevice, p->up);
+    }
+    if (e == hipSuccess && nspecial > 0)
+    {
+      e = hipMemcpyAsync(s.q->side, s.hostside, nspecial * (uint64_t) p->m,
+                         hipMemcpyHostToDevice, p->up);
+    }
+  } else
+  {
+    // what lies behind the last read must stop every comparison
+    memset(s.hostq + nsym, 0xFF, VSA_QUERY_BACKPAD);
+    if (e == hipSuccess)
+    {
+      e = hipMemcpyAsync(s.q->symbols, s.hostq, nsym + VSA_QUERY_BACKPAD,
+                         hipMemcpyHostToDevice, p->up);
+    }
   }
   if (e == hipSuccess)
   {
@@ -432,6 +570,7 @@ extern "C" int vsa_pipeline_submit(vsa_pipeline *p, uint64_t nq)
   p->wake.notify_all();
   return 0;
 }
+} // namespace
 
 // The matches of the oldest batch not delivered yet (host memory, valid until
 // the next call of vsa_pipeline_next / _hostbuffer that needs the slot).
@@ -597,6 +736,8 @@ extern "C" void vsa_pipeline_close(vsa_pipeline *p)
       vsa_result_free(s.res);
     }
     (void) hipHostFree(s.hostq);
+    (void) hipHostFree(s.hostrows);
+    (void) hipHostFree(s.hostside);
     (void) hipHostFree(s.hostm);
     vsa_queries_free(s.q);
     if (s.uploaded != nullptr)

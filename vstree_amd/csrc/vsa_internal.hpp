@@ -155,7 +155,21 @@ struct vsa_queries
 {
   int device;
   uint64_t nq, nsymbols;
-  uint8_t *symbols; // device, nsymbols + VSA_QUERY_BACKPAD
+  // Reads at two bits per symbol (vsa_queries_from_host_packed, the packed
+  // pipeline): rows != nullptr, roww 64-bit words per read, the reads with a
+  // special symbol as bytes in `side` (nside of them, uniform length each).
+  // `symbols` is then made on the device by the first call that needs bytes
+  // (vsa_queries_bytes: MEM, approximate matching, indexes without the deep
+  // tables) and kept.
+  uint64_t *rows = nullptr;
+  uint32_t roww = 0;
+  uint8_t *side = nullptr;
+  uint64_t nside = 0;
+  bool ownsrows = true;
+  mutable bool bytesvalid = false; // `symbols` holds this batch's bytes
+  uint64_t bytescapacity = 0;      // pipeline slots: symbols of the largest
+                                   // batch (0: this batch's)
+  mutable uint8_t *symbols; // device, nsymbols + VSA_QUERY_BACKPAD
   uint64_t *start;  // device [nq]
   uint64_t *length; // device [nq]
   // host copies of the lengths' summary, for validation without a sync
@@ -186,6 +200,11 @@ int vsa_unpack_result(const vsa_result *r, uint64_t count, vsa_match *device);
 // device-side view of a query batch
 struct DevQueries
 {
+  // packed batches: rows of roww words, see vsa_queries (symbols may be null)
+  const uint64_t *rows;
+  const uint8_t *side;
+  uint64_t nside; // reads in the side list (indexes are clamped to it)
+  uint32_t roww;
   const uint8_t *symbols;
   const uint64_t *start;
   const uint64_t *length;
@@ -198,6 +217,10 @@ struct DevQueries
 static inline DevQueries devqueries(const vsa_queries *q)
 {
   DevQueries d;
+  d.rows = q->rows;
+  d.side = q->side;
+  d.nside = q->nside;
+  d.roww = q->roww;
   d.symbols = q->symbols;
   d.start = q->start;
   d.length = q->length;
@@ -211,6 +234,16 @@ static inline DevQueries devqueries(const vsa_queries *q)
 }
 
 int vsa_set_device(int device);
+
+// words of a row of a packed batch of reads of m symbols: two bits per
+// symbol and a flag byte (include/vstree_amd.h, vsa_packed_words)
+static inline uint32_t vsa_rowwords(uint32_t m)
+{
+  return (2 * m + 8 + 63) / 64;
+}
+// the symbols of a packed batch as bytes on the device (made once, kept):
+// for the kernels that read bytes (api.hip)
+int vsa_queries_bytes(const vsa_queries *q, hipStream_t stream);
 
 // recycled device memory for temporaries and result lists (devmem.hip)
 int vsa_dev_alloc(void **ptr, size_t bytes);
