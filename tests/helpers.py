@@ -475,6 +475,69 @@ def write_fasta(path, records, width=60):
                 f.write(seq[i:i + width] + b"\n")
 
 
+def write_fasta_fast(path, records, width=60):
+    """the same file as write_fasta, written line matrix by line matrix (a
+    Python loop over the 1.7 M lines of a 100 Mbp record takes minutes)"""
+    letters = np.full(256, ord("n"), np.uint8)
+    letters[:4] = np.frombuffer(b"acgt", np.uint8)
+    with open(path, "wb") as f:
+        for desc, seq in records:
+            seq = letters[np.asarray(seq, np.uint8)]
+            f.write(b">" + desc.encode() + b"\n")
+            k = (len(seq) // width) * width
+            if k:
+                rows = seq[:k].reshape(-1, width)
+                nl = np.full((rows.shape[0], 1), 10, np.uint8)
+                f.write(np.hstack([rows, nl]).tobytes())
+            if k < len(seq):
+                f.write(seq[k:].tobytes() + b"\n")
+
+
+# Index-builder parity at the size SURVEY 8f-1 names: two texts whose index
+# files are too large to keep -- only the md5 of every file the reference's
+# mkvtree wrote is (tests/golden/bigindex.json, scripts/make_golden_big.py).
+# The texts come out of generators, here, so that the GPU test rebuilds the
+# very same FASTA files on the box.
+BIG_CASES = ("c100m", "r20m")
+
+
+def big_case_records(case):
+    """-> list of (description, codes) of the FASTA file of a big case"""
+    import vstree_amd as V
+    if case == "c100m":
+        # the synthetic genome of SURVEY 8d at 100 Mbp: uniform bases, one
+        # record
+        return [("synthetic_genome seed=42", V.synth_genome(100000000))]
+    if case == "r20m":
+        # 200 sequences, 20 Mbp: a 5 kb unit planted 300 times with a few
+        # substitutions each (lcp values in the thousands: llv), an exact
+        # tandem array, runs of wildcards, sequences of different lengths
+        rng = np.random.default_rng(20240)
+        lens = rng.integers(40000, 160000, 200)
+        lens = (lens * (20000000 / lens.sum())).astype(np.int64)
+        unit = rng.integers(0, 4, 5000).astype(np.uint8)
+        recs = []
+        for i, ln in enumerate(lens):
+            t = rng.integers(0, 4, int(ln)).astype(np.uint8)
+            for r in range(int(rng.integers(0, 4))):
+                if ln > 6000:
+                    p = int(rng.integers(0, ln - 5000))
+                    u = unit.copy()
+                    for e in range(int(rng.integers(0, 5))):
+                        u[int(rng.integers(0, 5000))] = rng.integers(0, 4)
+                    t[p:p + 5000] = u
+            if i % 17 == 3:
+                p = int(rng.integers(0, ln - 4000))
+                t[p:p + 3700] = np.tile(unit[:37], 100)
+            for r in range(int(rng.integers(0, 3))):
+                p = int(rng.integers(0, ln - 600))
+                t[p:p + int(rng.integers(1, 500))] = WILDCARD
+            recs.append(("seq%d planted repeats, wildcards len=%d" % (i, ln),
+                         t))
+        return recs
+    raise KeyError(case)
+
+
 # --------------------------------------------------------------------------
 # mkvtree index files
 # --------------------------------------------------------------------------

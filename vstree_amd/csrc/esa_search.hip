@@ -1095,7 +1095,9 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // made on the device once per batch
   const bool rows = queries->rows != nullptr && reduce && deepok &&
                     queries->roww <= 4;
-  if (queries->rows != nullptr && !rows)
+  const char *dbgrows = getenv("VSA_DEBUG_ROWS");
+  const int rowbits = dbgrows != nullptr ? atoi(dbgrows) : 7;
+  if (queries->rows != nullptr && (!rows || rowbits != 7))
   {
     if (vsa_queries_bytes(queries, stream) != 0)
     {
@@ -1114,7 +1116,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
     tfirst.start();
-    if (rows)
+    if (rows && (rowbits & 1))
     {
       k_mum_first<IDX, true, true, true>
           <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
@@ -1225,7 +1227,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         em.cursors = pcursor.as<unsigned long long>();
         em.packbits = packbits;
         em.valbits = valbits;
-        if (rows)
+        if (rows && (rowbits & 2))
         {
           k_mum_plan<IDX, true, true, true>
               <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
@@ -1329,7 +1331,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           ix, qs, dbase, perquery, nwork, searchlength,                       \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
-    if (fromplan && rows)
+    if (fromplan && rows && (rowbits & 4))
     {
       k_query_search_planned<IDX, 256, true, true>
           <<<vsa_grid(nplanblocks), 256, 0, stream>>>(

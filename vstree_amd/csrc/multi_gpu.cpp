@@ -166,6 +166,7 @@ struct vsa_multi
   std::vector<ncclComm_t> comms; // empty: counters are summed on the host
   std::vector<hipStream_t> streams;
   std::vector<unsigned long long *> counters; // device, 4 words per replica
+  std::vector<unsigned long long *> hcounters; // page-locked, 8 per replica
   int usedrccl = 0;
   Crew crew;
   std::vector<Exchange> xch;
@@ -201,11 +202,14 @@ void initcomms(vsa_multi *m)
   m->comms = comms;
   m->streams.resize(m->dev.size());
   m->counters.resize(m->dev.size());
+  m->hcounters.assign(m->dev.size(), nullptr);
   for (size_t r = 0; r < m->dev.size(); r++)
   {
     (void) hipSetDevice(m->dev[r]);
     (void) hipStreamCreateWithFlags(&m->streams[r], hipStreamNonBlocking);
     (void) hipMalloc((void **) &m->counters[r], 4 * sizeof(unsigned long long));
+    (void) hipHostMalloc((void **) &m->hcounters[r],
+                         8 * sizeof(unsigned long long), hipHostMallocDefault);
   }
 }
 
@@ -219,16 +223,25 @@ int reducecounters(vsa_multi *m, const std::vector<vsa_stats> &st,
   m->usedrccl = 0;
   if (!m->comms.empty())
   {
+    // in: page-locked words -> device (async); the all-reduce on the same
+    // stream; out: device -> page-locked words of replica 0; ONE wait per
+    // replica for all of it
     bool ok = true;
     for (size_t r = 0; r < world && ok; r++)
     {
-      const unsigned long long mine[4] = {
-          st[r].count, st[r].sumlength, st[r].searches,
-          st[r].candidates};
-      ok = hipSetDevice(m->dev[r]) == hipSuccess &&
-           hipMemcpyAsync(m->counters[r], mine, sizeof mine,
-                          hipMemcpyHostToDevice, m->streams[r]) == hipSuccess &&
-           hipStreamSynchronize(m->streams[r]) == hipSuccess;
+      unsigned long long *h = m->hcounters[r];
+      ok = h != nullptr;
+      if (ok)
+      {
+        h[0] = st[r].count;
+        h[1] = st[r].sumlength;
+        h[2] = st[r].searches;
+        h[3] = st[r].candidates;
+        ok = hipSetDevice(m->dev[r]) == hipSuccess &&
+             hipMemcpyAsync(m->counters[r], h, 4 * sizeof *h,
+                            hipMemcpyHostToDevice, m->streams[r]) ==
+                 hipSuccess;
+      }
     }
     if (ok)
     {
@@ -240,6 +253,13 @@ int reducecounters(vsa_multi *m, const std::vector<vsa_stats> &st,
       }
       ok = ncclGroupEnd() == ncclSuccess && ok;
     }
+    if (ok)
+    {
+      ok = hipSetDevice(m->dev[0]) == hipSuccess &&
+           hipMemcpyAsync(m->hcounters[0] + 4, m->counters[0],
+                          4 * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, m->streams[0]) == hipSuccess;
+    }
     for (size_t r = 0; r < world && ok; r++)
     {
       ok = hipSetDevice(m->dev[r]) == hipSuccess &&
@@ -247,9 +267,7 @@ int reducecounters(vsa_multi *m, const std::vector<vsa_stats> &st,
     }
     if (ok)
     {
-      ok = hipSetDevice(m->dev[0]) == hipSuccess &&
-           hipMemcpy(sum, m->counters[0], sizeof sum,
-                     hipMemcpyDeviceToHost) == hipSuccess;
+      memcpy(sum, m->hcounters[0] + 4, sizeof sum);
     }
     if (!ok)
     {
@@ -670,6 +688,7 @@ extern "C" void vsa_multi_close(vsa_multi *m)
     (void) ncclCommDestroy(m->comms[r]);
     (void) hipStreamDestroy(m->streams[r]);
     (void) hipFree(m->counters[r]);
+    (void) hipHostFree(m->hcounters[r]);
   }
   for (vsa_index *ix : m->ix)
   {
