@@ -312,10 +312,10 @@ __device__ __forceinline__ uint32_t vsa_pack16(uint64_t a, uint64_t b)
 // leaves in lcplen what COMPARE / CHECKRETURN (kurtz/maxpref.c:30-65) would:
 // the position of the first mismatch, of the first special symbol of the
 // query, or querylen.  CHUNKS: pieces of 60 symbols fetched per round trip.
-template <int CHUNKS, typename IDX>
+template <int CHUNKS, typename IDX, typename QP = const uint8_t *>
 __device__ __forceinline__ bool
-vsa_extend_packed(const DevIndex<IDX> &ix, uint64_t sufstart,
-                  const uint8_t *query, uint32_t querylen, uint32_t &lcplen)
+vsa_extend_packed(const DevIndex<IDX> &ix, uint64_t sufstart, QP query,
+                  uint32_t querylen, uint32_t &lcplen)
 {
   const uint32_t from = lcplen;
   uint32_t l = lcplen, qeff = querylen;
@@ -569,6 +569,50 @@ __device__ __forceinline__ void vsa_pq_from_row(const DevQueries &qs,
     }
     pq.valid = firstbad;
   }
+}
+
+// A read of a packed batch for the kernels whose work-item looks at a window
+// of it (work plan, search kernel): nothing but the row's address travels in
+// registers, every window is one 16-byte load of the row (a cache hit for all
+// but the first of a read's work-items).  Only for reads WITHOUT a special
+// symbol: `valid` = the read's length.  (A PackedQuery's `valid` is the
+// position of its FIRST special symbol -- right for a search that starts at
+// symbol 0, wrong for the suffixes behind the symbol; reads with one take the
+// byte path through their QSrc instead.)
+struct RowQuery
+{
+  const uint64_t *row;
+  uint32_t valid;
+};
+
+__device__ __forceinline__ uint64_t vsa_pq_window(const RowQuery &rq,
+                                                  uint32_t at)
+{
+  const uint32_t i = at >> 5, sh = 2u * (at & 31u);
+  const vsa_u128 w = vsa_load16(rq.row + i);
+  return sh != 0 ? (w.lo << sh) | (w.hi >> (64 - sh)) : w.lo;
+}
+
+// the row of read q, its flag (a read with a special symbol), and the QSrc
+// of the read: its bytes in the side list if flagged, the row otherwise
+__device__ __forceinline__ bool vsa_row_of(const DevQueries &qs, uint64_t q,
+                                           uint32_t m, RowQuery &rq,
+                                           QSrc &src)
+{
+  const uint32_t W = qs.roww;
+  rq.row = qs.rows + q * W;
+  rq.valid = m;
+  src.row = rq.row;
+  src.bytes = nullptr;
+  src.pos = 0;
+  src.m = (int32_t) m;
+  const bool flagged = (rq.row[W - 1] & 0xFFu) != 0 && qs.nside > 0;
+  if (flagged)
+  {
+    const uint64_t k = rq.row[0] < qs.nside ? rq.row[0] : qs.nside - 1;
+    src.bytes = qs.side + k * (uint64_t) m;
+  }
+  return flagged;
 }
 
 // symbol i of a packed query (i < 128)
