@@ -96,7 +96,7 @@ def parse():
                     help="queries timed on one CPU core (0 = no CPU baseline)")
     ap.add_argument("--ref-sample", type=int, default=2000000,
                     help="queries given to the P reference processes together")
-    ap.add_argument("--reads", choices=("packed", "bytes"), default="bytes",
+    ap.add_argument("--reads", choices=("packed", "bytes"), default="packed",
                     help="how the query batch lies in HBM: the reference's "
                          "Multiseq bytes, or two bits per symbol "
                          "(vsa_pack_reads)")
@@ -125,9 +125,13 @@ def parse():
                          "per GPU (libvstree_amd_multi.so); torch = one "
                          "process per GPU over torch.distributed")
     ap.add_argument("--host", action="store_true",
-                    help="--path c: time the host-memory entry "
-                         "(vsa_multi_findmatches) instead of the "
-                         "device-resident one")
+                    help="--path c: time the host-memory entries instead of "
+                         "the device-resident one: vsa_multi_pipeline_* "
+                         "(packed rows in page-locked slots)")
+    ap.add_argument("--compat", action="store_true",
+                    help="--path c --host: vsa_multi_findmatches (a Multiseq "
+                         "in pageable memory, one list back) instead of the "
+                         "pipelines")
     # --path c on a box with one GPU: N replicas of the index on device 0
     ap.add_argument("--replicas-on-one-gpu", action="store_true")
     return ap.parse_args()
@@ -455,6 +459,11 @@ def c_path_mode(a, jsonfd, rank, world):
             devices[0]))
         if a.host:
             V.device_download(hq[r * nq * m:(r + 1) * nq * m], dq, devices[0])
+        elif a.reads == "packed":
+            V.device_download(hblock, dq, devices[0])
+            b = V.Queries.from_host_packed(hblock, m, devices[r])
+            b.set_offset(r * nq)
+            blocks.append(b)
         elif devices[r] == devices[0]:
             b = V.Queries.from_device(dq, nq, m, devices[r])
             b.set_offset(r * nq)
@@ -477,8 +486,36 @@ def c_path_mode(a, jsonfd, rank, world):
     length = np.full(nq * N, m, np.uint64)
     kernel_ms, first_ms = [], []
 
+    mp, slotns = None, {}
+    if a.host and not a.compat:
+        # vsa_multi_pipeline_*: a packed pipeline per replica; a step = one
+        # -mum job of one batch per replica; the slots' page-locked rows are
+        # packed before the clock starts (a slot keeps its reads)
+        mp = M.MultiPipeline(multi, M.MUM, L, m, nq, maxspecial=1024)
+
+    def pipeline_job():
+        for r in range(N):
+            got = mp.hostrows()
+            assert got is not None
+            rows, special = got
+            key = rows.ctypes.data
+            if key not in slotns:
+                ns = C.c_uint64(0)
+                V._check(V.lib.vsa_pack_reads(
+                    hq[r * nq * m:].ctypes.data, nq, m, m, rows.ctypes.data,
+                    special.ctypes.data, mp.maxspecial, C.byref(ns)))
+                slotns[key] = int(ns.value)
+            mp.submit(nq, slotns[key])
+        while mp.next(copy=False)[0] != 1:
+            pass
+        lists, st = mp.finish(copy=False)
+        assert sum(len(x) for x in lists) == st.count
+        return st
+
     def one_step():
-        if a.host:
+        if mp is not None:
+            st, rc, msg = pipeline_job(), 0, ""
+        elif a.host:
             mm, st, rc, msg = multi.findmatches(M.MUM, hq, start, length, L)
         else:
             res, st, rc, msg = multi.findmatches_device(M.MUM, blocks, L)
@@ -498,8 +535,8 @@ def c_path_mode(a, jsonfd, rank, world):
             dist.barrier()
 
     st = None
-    for _ in range(a.warmup):
-        st = one_step()
+    for _ in range(max(a.warmup, 3) if mp is not None else a.warmup):
+        st = one_step()         # (a pipeline: all three slots of a replica)
     kernel_ms.clear()
     first_ms.clear()
     sync()
@@ -509,7 +546,11 @@ def c_path_mode(a, jsonfd, rank, world):
     sync()
     elapsed = time.perf_counter() - t0
     kms = float(np.mean(kernel_ms))
-    what = ("host memory to host memory through vsa_multi_findmatches -- "
+    what = ("host memory to host memory through vsa_multi_pipeline_* (packed "
+            "rows in page-locked slots, three batches in flight per GPU) -- "
+            "PCIe-inclusive" if mp is not None else
+            "host memory to host memory through vsa_multi_findmatches (a "
+            "Multiseq in pageable memory in, one malloc'ed list out) -- "
             "PCIe-inclusive" if a.host else
             "queries and match lists resident in HBM, "
             "vsa_multi_findmatches_device")
@@ -531,6 +572,7 @@ def c_path_mode(a, jsonfd, rank, world):
                    "index_bp": n, "queries_per_gpu": nq, "query_len": m,
                    "minlen": L, "prefixlength": info.prefixlength,
                    "deepprefix": info.deepprefix,
+                   "reads_in_hbm": a.reads,
                    "index_bytes_hbm": info.device_bytes,
                    "index_build_s": round(t_index, 2),
                    "devices": devices,
@@ -557,6 +599,8 @@ def c_path_mode(a, jsonfd, rank, world):
     if a.host:
         out["bytes_over_pcie_per_step"] = int(nq * N * m + 16 * nq * N +
                                               32 * int(st.count))
+    if mp is not None:
+        mp.close()
     multi.close()
     os.write(jsonfd, (json.dumps(out) + "\n").encode())
     if dist is not None:
@@ -660,10 +704,12 @@ def main():
                                             sub.ctypes.data,
                                             step.ctypes.data, nq, m, dq, dev))
     queries = V.Queries.from_device(dq, nq, m, dev)
+    bytequeries = None
     if a.reads == "packed":
         hq = np.empty(nq * m, np.uint8)
         V.device_download(hq, dq, dev)
-        queries.close()
+        bytequeries = queries      # (timed for comparison behind the steps)
+        bytequeries.set_offset(rank * nq)
         queries = V.Queries.from_host_packed(hq, m, dev)
         del hq
     queries.set_offset(rank * nq)
@@ -807,6 +853,29 @@ def main():
         elapsed = float(e.item())
 
     count, sumlength, searches, candidates, kernel_searches = totals
+    bytes_form = None
+    if bytequeries is not None and not distributed:
+        # the same batch as the reference's Multiseq bytes, a few steps
+        V.device_synchronize(dev)
+        tb = time.perf_counter()
+        for _ in range(max(3, a.steps // 4)):
+            r = V.findquerymatches(index, bytequeries, L, mum=True)
+            sb = r.stats()
+            r.close()
+        V.device_synchronize(dev)
+        tb = (time.perf_counter() - tb) / max(3, a.steps // 4)
+        if (sb.count, sb.sumlength, sb.candidates) != (count, sumlength,
+                                                       candidates):
+            raise RuntimeError("bench.py: the packed and the byte batch of "
+                               "the same reads disagree")
+        bytes_form = {"ms_per_step": tb * 1e3, "value": nq / tb,
+                      "search_kernel_ms": sb.search_kernel_ms,
+                      "first_pass_ms": sb.first_kernel_ms,
+                      "what": "the same reads resident as one byte per symbol "
+                              "(the reference's Multiseq, round 3's form): "
+                              "same counters"}
+    if bytequeries is not None:
+        bytequeries.close()
     total_queries = nq * world
     qps = total_queries * a.steps / elapsed
     kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -845,6 +914,8 @@ def main():
                        if distributed and not a.rehearse_on_one_gpu else 0),
         "ranks": world,
     }
+    if bytes_form is not None:
+        out["reads_as_bytes"] = bytes_form
 
     if rank == 0:
         import helpers as H  # test infrastructure: the CPU oracle
@@ -1237,8 +1308,11 @@ def cpu_baselines(a, V, H, index, host, qsym, m, L, dev, qps, free_index):
     ref = H.oracle_querymatches(host, sample, L, mum=True, speedup=2)
     dt = time.perf_counter() - t0
     # the same sample as a batch of its own on the GPU: identical list
-    gsample = V.Queries.from_host(sample.symbols, sample.start, sample.length,
-                                  dev)
+    if a.reads == "packed":
+        gsample = V.Queries.from_host_packed(sample.symbols, m, dev)
+    else:
+        gsample = V.Queries.from_host(sample.symbols, sample.start,
+                                      sample.length, dev)
     gres = V.findquerymatches(index, gsample, L, mum=True)
     same = bool(np.array_equal(gres.fetch(), ref))
     gres.close()

@@ -630,6 +630,26 @@ int vsa_pipeline_finish(vsa_pipeline *pipeline, const vsa_match **matches,
                         uint64_t *count, vsa_stats *stats);
 void vsa_pipeline_close(vsa_pipeline *pipeline);
 
+/* For a caller that runs one pipeline per GPU and deals the batches of a job
+   out to them (include/vstree_amd_multi.h, vsa_multi_pipeline_*):
+   vsa_pipeline_set_offset: the number the first query of the NEXT submitted
+   batch gets.  vsa_pipeline_take_candidates (-mum pipelines, all batches
+   taken): the candidate rows of the job where they lie in device memory -- 16
+   bytes each, sort key dbstart << lengthbits | (2^lengthbits - 1 - length) and
+   value queryseq << 16 | querystart, valid until the next batch is submitted
+   -- instead of vsa_pipeline_finish; ends the job.
+   vsa_rows_partition_device: such rows grouped by the range of the index
+   their dbstart falls into, like vsa_result_partition_device (same stream
+   contract: the device's default stream). */
+int vsa_pipeline_set_offset(vsa_pipeline *pipeline, uint64_t firstquery);
+int vsa_pipeline_take_candidates(vsa_pipeline *pipeline,
+                                 const void **device_rows, uint64_t *nrows,
+                                 uint32_t *lengthbits);
+int vsa_rows_partition_device(const void *device_rows, uint64_t nrows,
+                              uint32_t lengthbits, uint32_t nparts,
+                              int ownpart, uint64_t totallength, int device,
+                              void *device_out, uint64_t *device_meta);
+
 /* ---- synthetic inputs (bench.py, tests): SURVEY.md section 8d ---------- */
 
 uint64_t vsa_splitmix64_at(uint64_t seed, uint64_t idx);

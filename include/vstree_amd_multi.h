@@ -104,6 +104,51 @@ int vsa_multi_findmatches_device(vsa_multi *multi, int mode,
                                  vsa_queries *const *blocks,
                                  vsa_result **results, vsa_stats *total);
 
+/*
+  Host memory to host memory at the rate of the GPUs: one packed pipeline
+  (vsa_pipeline_open_packed: page-locked slots the caller packs its reads into
+  with vsa_pack_reads, three batches in flight per GPU, upload / search /
+  download overlapped) per replica.  The batches of a job are dealt out to
+  the replicas in turn and are delivered in the order they were submitted --
+  query order, the reference's order for -complete, -l and -mum cand
+  (Vmengine/fcomplete.c:313-319, Vmengine/fquery.c:468-475); queryseq counts
+  over the whole job.  Calls mirror vsa_pipeline_* (one calling thread):
+
+    vsa_multi_pipeline_open(multi, VSA_MULTI_MUM, 20, 100, 4000000, 65536, &p);
+    while (more reads) {
+      while (vsa_multi_pipeline_hostrows(p, &rows, &special) == 1)
+        vsa_multi_pipeline_next(p, &matches, &n);     -- take a finished batch
+      ns = 0; vsa_pack_reads(reads, nq, 100, stride, rows, special, 65536, &ns);
+      vsa_multi_pipeline_submit(p, nq, ns);
+    }
+    while (vsa_multi_pipeline_next(p, &matches, &n) != 1) ...;
+    vsa_multi_pipeline_finish(p, lists, counts, &total);      -- -mum only
+
+  -mum: the batches deliver nothing; the candidates stay in the HBM of the
+  replica that found them, and vsa_multi_pipeline_finish runs the filter of
+  kurtz/cleanMUMcand.c:55-118 over all of them -- grouped by range of the
+  index, range r moved to GPU r by peer copies, filtered there -- and leaves
+  list r (ascending dbstart; the lists in replica order are the reference's
+  list) in page-locked host memory that stays valid until the next finish or
+  close: lists[r], counts[r] for r < vsa_multi_ndevices.  The counters of the
+  job take the one ncclAllReduce.
+*/
+typedef struct vsa_multi_pipeline vsa_multi_pipeline;
+int vsa_multi_pipeline_open(vsa_multi *multi, int mode, uint64_t searchlength,
+                            uint32_t querylength, uint64_t maxqueries,
+                            uint64_t maxspecial,
+                            vsa_multi_pipeline **pipeline);
+int vsa_multi_pipeline_hostrows(vsa_multi_pipeline *pipeline, uint64_t **rows,
+                                uint8_t **special);
+int vsa_multi_pipeline_submit(vsa_multi_pipeline *pipeline,
+                              uint64_t numofqueries, uint64_t numofspecial);
+int vsa_multi_pipeline_next(vsa_multi_pipeline *pipeline,
+                            const vsa_match **matches, uint64_t *count);
+int vsa_multi_pipeline_finish(vsa_multi_pipeline *pipeline,
+                              const vsa_match **lists, uint64_t *counts,
+                              vsa_stats *total);
+void vsa_multi_pipeline_close(vsa_multi_pipeline *pipeline);
+
 /* the same with the reference's delivery model: callbacks on the calling
    thread, in reference order, stop on a non-zero return */
 int vsa_multi_findmatches_cb(vsa_multi *multi, int mode,

@@ -165,6 +165,63 @@ def test_device_form_errors_follow_the_reference(V, MG):
     m.close()
 
 
+@pytest.mark.parametrize("world,per", [(1, 3000), (2, 999), (3, 2500),
+                                       (5, 640)])
+def test_multi_pipeline_deals_batches_out_and_keeps_the_order(V, MG, world,
+                                                              per):
+    """vsa_multi_pipeline_*: packed batches from host memory, dealt out to
+    the replicas in turn; the lists come back in submission order = query
+    order; -mum filters over the candidates of all replicas at the end"""
+    idx, q, m = tables(MG, "c1", [0] * world)
+    m.set_queryspeedup(2)
+    ql = int(q.length[0])
+    sym = q.symbols.copy()
+    sym[np.random.default_rng(3).integers(0, len(sym), 300)] = H.WILDCARD
+    hq = H.Queries.uniform(sym, ql)
+    for mode, kw in ((MG.COMPLETE, None), (MG.MUMCAND, dict(mum=True,
+                                                            cand=True)),
+                     (MG.MEM, dict()), (MG.MUM, dict(mum=True))):
+        p = MG.MultiPipeline(m, mode, 20, ql, per, maxspecial=per)
+        out, first = [], 0
+        while first < hq.nq:
+            n = min(per, hq.nq - first)
+            while not p.pack_into_slot(sym[first * ql:(first + n) * ql], n):
+                rc, got = p.next()
+                assert rc == 0
+                out.append(got)
+            first += n
+        while True:
+            rc, got = p.next()
+            if rc == 1:
+                break
+            assert rc == 0
+            out.append(got)
+        got = np.concatenate(out) if out else np.zeros(0, MG.MATCH_DTYPE)
+        if mode == MG.MUM:
+            assert len(got) == 0
+            lists, st = p.finish()
+            got = np.concatenate(lists)
+            assert st.count == len(got)
+            for r, l in enumerate(lists):
+                part = (l["dbstart"].astype(object) * world) // (idx.n + 1)
+                assert all(x == r for x in part)
+        want = (H.oracle_complete(idx, hq) if kw is None else
+                H.oracle_querymatches(idx, hq, 20, speedup=2, **kw))
+        assert np.array_equal(got, want), (world, per, mode)
+        # a second job through the same pipelines: the numbering starts again
+        if mode == MG.MUM:
+            assert p.pack_into_slot(sym[:per * ql], min(per, hq.nq))
+            while p.next()[0] != 1:
+                pass
+            lists, st = p.finish()
+            want = H.oracle_querymatches(
+                idx, H.Queries.uniform(sym[:min(per, hq.nq) * ql], ql), 20,
+                speedup=2, mum=True)
+            assert np.array_equal(np.concatenate(lists), want)
+        p.close()
+    m.close()
+
+
 def test_one_replica_sums_its_counters_through_rccl(V, MG):
     """a communicator of one rank: the ncclAllReduce path runs for real"""
     idx, q, m = tables(MG, "micro", [0])
@@ -340,9 +397,14 @@ def test_bench_c_path_with_replicas_on_one_gpu():
     assert a["n_gpus"] == 2 and "resident in HBM" in a["config"]["path"]
     assert "30 Mbp" in a["config"]["workload"]
     assert h["n_gpus"] == 2 and "host memory" in h["metric"]
-    for x in (a, h):
+    assert "vsa_multi_pipeline" in h["config"]["path"]
+    c = run("--gpus", "2", "--path", "c", "--host", "--compat",
+            "--replicas-on-one-gpu", "--queries", "150000")
+    assert "vsa_multi_findmatches" in c["config"]["path"]
+    for x in (a, h, c):
         assert x["matches"] == b["matches"] > 250000
         assert x["candidates"] == b["candidates"]
+    for x in (a, c):
         assert x["query_suffix_searches"] == b["query_suffix_searches"]
 
 

@@ -137,6 +137,11 @@ def _load():
         "vsa_pipeline_finish": (I, [V, PP, C.POINTER(U64),
                                     C.POINTER(Stats)]),
         "vsa_pipeline_close": (None, [V]),
+        "vsa_pipeline_set_offset": (I, [V, U64]),
+        "vsa_pipeline_take_candidates": (I, [V, PP, C.POINTER(U64),
+                                             C.POINTER(U32)]),
+        "vsa_rows_partition_device": (I, [V, U64, U32, U32, I, U64, I, V,
+                                          V]),
         "vsa_mkvtree": (I, [C.POINTER(C.c_char_p), U32, C.POINTER(C.c_char_p),
                             U32, C.c_char_p, U32, U32, I, I]),
         "vsa_queries_from_host": (I, [V, U64, V, V, U64, I, PP]),

@@ -2229,6 +2229,7 @@ struct PartInput
 {
   const vsa_match *m;
   const uint64_t *key, *val;
+  uint32_t stride; // 1: keys and values in arrays of their own; 2: in rows
   uint32_t packbits;
   // the part written behind all others (a rank's own: it does not travel),
   // its place among the parts and the number of parts; own = nparts: none
@@ -2245,7 +2246,7 @@ __device__ __forceinline__ void part_read(const PartInput &in, uint64_t t,
 {
   if (in.packbits != 0)
   {
-    const uint64_t k = in.key[t], mask = (1ull << in.packbits) - 1;
+    const uint64_t k = in.key[t * in.stride], mask = (1ull << in.packbits) - 1;
     dbstart = k >> in.packbits;
     length = mask - (k & mask);
   } else
@@ -2350,7 +2351,7 @@ k_partition_place(const PartInput in, uint64_t n,
   if (t < n && in.packbits != 0)
   {
     // rows of two words: key, value
-    const uint64_t k = in.key[t], v = in.val[t];
+    const uint64_t k = in.key[t * in.stride], v = in.val[t * in.stride];
     const uint32_t p = in.place(
         (uint32_t) (((k >> in.packbits) * nparts) / (totallength + 1)));
     const uint64_t slot = offsets[(uint64_t) p * nblocks + vsa_bid()] +
@@ -2566,7 +2567,7 @@ k_partition_place_small(const PartInput in, uint64_t n, uint32_t nparts,
     row[i] = make_uint4(0, 0, 0, 0);
     if (t < n)
     {
-      const uint64_t k = in.key[t], v = in.val[t];
+      const uint64_t k = in.key[t * in.stride], v = in.val[t * in.stride];
       row[i] = make_uint4((uint32_t) k, (uint32_t) (k >> 32), (uint32_t) v,
                           (uint32_t) (v >> 32));
       p = in.place(pb.part(k >> in.packbits));
@@ -2762,6 +2763,13 @@ int partition_impl(const vsa_result *result, uint32_t nparts, int ownpart,
   in.m = result->matches;
   in.key = reinterpret_cast<const uint64_t *>(result->matches);
   in.val = result->packvals;
+  in.stride = 1;
+  if (result->packbits != 0 && result->packvals == nullptr)
+  {
+    // rows of (key, value) pairs (vsa_rows_partition_device)
+    in.val = in.key + 1;
+    in.stride = 2;
+  }
   in.packbits = result->packbits;
   in.nparts = nparts;
   in.own = ownpart < 0 ? nparts : (uint32_t) ownpart;
@@ -2833,6 +2841,32 @@ int partition_impl(const vsa_result *result, uint32_t nparts, int ownpart,
 }
 
 } // namespace
+
+extern "C" int vsa_rows_partition_device(const void *device_rows,
+                                         uint64_t nrows, uint32_t lengthbits,
+                                         uint32_t nparts, int ownpart,
+                                         uint64_t totallength, int device,
+                                         void *device_out,
+                                         uint64_t *device_meta)
+{
+  if ((nrows > 0 && device_rows == nullptr) || device_meta == nullptr ||
+      lengthbits == 0 || lengthbits > 16)
+  {
+    VSA_ERROR("vsa_rows_partition_device: bad argument");
+    return -1;
+  }
+  // the rows seen as a packed result whose values lie next to their keys
+  vsa_result view;
+  view.device = device;
+  view.count = nrows;
+  view.matches =
+      reinterpret_cast<vsa_match *>(const_cast<void *>(device_rows));
+  memset(&view.stats, 0, sizeof view.stats);
+  view.packbits = lengthbits;
+  view.packvals = nullptr;
+  return partition_impl(&view, nparts, ownpart, totallength, device_out,
+                        nullptr, nullptr, device_meta);
+}
 
 extern "C" int vsa_result_partition(const vsa_result *result, uint32_t nparts,
                                     uint64_t totallength,

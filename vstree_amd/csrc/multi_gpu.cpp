@@ -1299,3 +1299,314 @@ extern "C" int vsa_multi_findmatches_device(vsa_multi *m, int mode,
   }
   return reducecounters(m, st, total);
 }
+
+// ---- host memory to host memory over all replicas ----------------------------
+// One packed pipeline (vsa_pipeline_open_packed: page-locked slots, three
+// batches in flight, upload / search / download overlapped) per replica; the
+// batches of a job are dealt out to the replicas in turn and come back in
+// the order they were submitted, which is query order -- the reference's
+// order for -complete, -l and -mum cand.  -mum: the candidates of a replica's
+// batches stay in its HBM; vsa_multi_pipeline_finish groups them by range,
+// moves range r to GPU r (peer copies) and filters there, like the
+// device-resident form.
+
+struct vsa_multi_pipeline
+{
+  vsa_multi *m = nullptr;
+  int mode = 0;
+  uint32_t qlen = 0;
+  uint64_t submitted = 0; // queries of the job so far
+  uint64_t batches = 0;   // batches of the job so far: the next one goes to
+                          // replica batches % ndevices
+  std::vector<vsa_pipeline *> pipes;
+  std::vector<uint32_t> order; // replicas of the batches not yet delivered
+  size_t delivered = 0;
+  // -mum: the lists of the replicas in page-locked memory, kept between jobs
+  std::vector<vsa_match *> hostlist;
+  std::vector<uint64_t> hostcap;
+};
+
+extern "C" void vsa_multi_pipeline_close(vsa_multi_pipeline *p)
+{
+  if (p == nullptr)
+  {
+    return;
+  }
+  for (size_t r = 0; r < p->pipes.size(); r++)
+  {
+    vsa_pipeline_close(p->pipes[r]);
+    if (r < p->hostlist.size() && p->hostlist[r] != nullptr)
+    {
+      (void) hipHostFree(p->hostlist[r]);
+    }
+  }
+  delete p;
+}
+
+extern "C" int vsa_multi_pipeline_open(vsa_multi *m, int mode,
+                                       uint64_t searchlength,
+                                       uint32_t querylength,
+                                       uint64_t maxqueries,
+                                       uint64_t maxspecial,
+                                       vsa_multi_pipeline **pipeline)
+{
+  if (m == nullptr || pipeline == nullptr || mode < 0 ||
+      mode > VSA_MULTI_MUM)
+  {
+    seterror("vsa_multi_pipeline_open: bad argument");
+    return -1;
+  }
+  *pipeline = nullptr;
+  vsa_multi_pipeline *p = new vsa_multi_pipeline;
+  const uint32_t world = (uint32_t) m->dev.size();
+  p->m = m;
+  p->mode = mode;
+  p->qlen = querylength;
+  p->pipes.assign(world, nullptr);
+  p->hostlist.assign(world, nullptr);
+  p->hostcap.assign(world, 0);
+  for (uint32_t r = 0; r < world; r++)
+  {
+    const int rc = vsa_pipeline_open_packed(m->ix[r], mode, searchlength,
+                                            querylength, maxqueries,
+                                            maxspecial, &p->pipes[r]);
+    if (rc != 0)
+    {
+      vsa_multi_pipeline_close(p);
+      return rc;
+    }
+  }
+  *pipeline = p;
+  return 0;
+}
+
+extern "C" int vsa_multi_pipeline_hostrows(vsa_multi_pipeline *p,
+                                           uint64_t **rows, uint8_t **special)
+{
+  if (p == nullptr)
+  {
+    seterror("vsa_multi_pipeline_hostrows: NULL argument");
+    return -1;
+  }
+  return vsa_pipeline_hostrows(p->pipes[p->batches % p->pipes.size()], rows,
+                               special);
+}
+
+extern "C" int vsa_multi_pipeline_submit(vsa_multi_pipeline *p,
+                                         uint64_t numofqueries,
+                                         uint64_t numofspecial)
+{
+  if (p == nullptr)
+  {
+    seterror("vsa_multi_pipeline_submit: NULL argument");
+    return -1;
+  }
+  const uint32_t r = (uint32_t) (p->batches % p->pipes.size());
+  int rc = vsa_pipeline_set_offset(p->pipes[r], p->submitted);
+  if (rc == 0)
+  {
+    rc = vsa_pipeline_submit_packed(p->pipes[r], numofqueries, numofspecial);
+  }
+  if (rc == 0)
+  {
+    p->order.push_back(r);
+    p->batches++;
+    p->submitted += numofqueries;
+  }
+  return rc;
+}
+
+extern "C" int vsa_multi_pipeline_next(vsa_multi_pipeline *p,
+                                       const vsa_match **matches,
+                                       uint64_t *count)
+{
+  if (p == nullptr || matches == nullptr || count == nullptr)
+  {
+    seterror("vsa_multi_pipeline_next: NULL argument");
+    return -1;
+  }
+  *matches = nullptr;
+  *count = 0;
+  if (p->delivered == p->order.size())
+  {
+    return 1;
+  }
+  const uint32_t r = p->order[p->delivered++];
+  if (p->delivered == p->order.size())
+  {
+    p->order.clear();
+    p->delivered = 0;
+  }
+  return vsa_pipeline_next(p->pipes[r], matches, count);
+}
+
+namespace
+{
+
+// range r: peer copies of its rows from every other replica, then the filter
+// over r's own rows and the received ones (devicefilter, on the rows of a
+// pipeline job instead of a search call)
+void pipelinefilter(vsa_multi *m, uint32_t r, uint32_t lengthbits,
+                    uint64_t totallength, const std::vector<uint64_t> &nrows,
+                    DeviceOut &o, vsa_result **result)
+{
+  vsa_queries *noblocks[1] = {nullptr};
+  DeviceJob job;
+  job.m = m;
+  job.mode = VSA_MULTI_MUM;
+  job.searchlength = 0;
+  job.totallength = totallength;
+  job.lengthbits = lengthbits;
+  job.blocks = noblocks;
+  std::vector<vsa_result *> results(m->dev.size(), nullptr);
+  job.results = results.data();
+  std::vector<DeviceOut> found(m->dev.size());
+  for (size_t s = 0; s < found.size(); s++)
+  {
+    memset(&found[s].stats, 0, sizeof found[s].stats);
+    found[s].ncand = nrows[s];
+  }
+  devicefilter(job, r, found, o);
+  *result = results[r];
+}
+
+} // namespace
+
+extern "C" int vsa_multi_pipeline_finish(vsa_multi_pipeline *p,
+                                         const vsa_match **lists,
+                                         uint64_t *counts, vsa_stats *total)
+{
+  if (p == nullptr || lists == nullptr || counts == nullptr ||
+      p->mode != VSA_MULTI_MUM)
+  {
+    seterror("vsa_multi_pipeline_finish: bad argument (a -mum pipeline?)");
+    return -1;
+  }
+  vsa_multi *m = p->m;
+  const uint32_t world = (uint32_t) m->dev.size();
+  vsa_index_info info;
+  if (vsa_index_getinfo(m->ix[0], &info) != 0)
+  {
+    return -1;
+  }
+  for (uint32_t r = 0; r < world; r++)
+  {
+    lists[r] = nullptr;
+    counts[r] = 0;
+  }
+  p->submitted = 0;
+  p->batches = 0;
+  // phase 1: every replica groups the candidates of its batches by range
+  std::vector<DeviceOut> grouped(world), filtered(world);
+  std::vector<uint64_t> nrows(world, 0);
+  std::vector<uint32_t> bits(world, 0);
+  m->crew.run([&](uint32_t r) {
+    DeviceOut &o = grouped[r];
+    Exchange &x = m->xch[r];
+    const void *rows = nullptr;
+    memset(&o.stats, 0, sizeof o.stats);
+    if (hipSetDevice(m->dev[r]) != hipSuccess)
+    {
+      (void) fail(o, -100, "hipSetDevice failed");
+      return;
+    }
+    int rc = vsa_pipeline_take_candidates(p->pipes[r], &rows, &nrows[r],
+                                          &bits[r]);
+    if (rc != 0)
+    {
+      (void) fail(o, rc, nullptr);
+      return;
+    }
+    if (x.devmeta == nullptr &&
+        (vsa_device_malloc(2 * (uint64_t) world * 8, m->dev[r],
+                           (void **) &x.devmeta) != 0 ||
+         hipHostMalloc((void **) &x.hostmeta, 2 * (size_t) world * 8,
+                       hipHostMallocDefault) != hipSuccess ||
+         hipStreamCreateWithFlags(&x.copy, hipStreamNonBlocking) !=
+             hipSuccess))
+    {
+      (void) fail(o, -100, "vsa_multi: no memory for the exchange state");
+      return;
+    }
+    if (growrows(&x.rows, &x.rowcap, nrows[r], m->dev[r]) != 0)
+    {
+      (void) fail(o, -100, nullptr);
+      return;
+    }
+    rc = vsa_rows_partition_device(rows, nrows[r], bits[r], world, (int) r,
+                                   info.totallength, m->dev[r], x.rows,
+                                   x.devmeta);
+    if (rc != 0)
+    {
+      (void) fail(o, rc, nullptr);
+      return;
+    }
+    if (hipMemcpyAsync(x.hostmeta, x.devmeta, 2 * (size_t) world * 8,
+                       hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess)
+    {
+      (void) fail(o, -100, "vsa_multi: split sizes did not arrive");
+    }
+  });
+  for (uint32_t r = 0; r < world; r++)
+  {
+    if (grouped[r].rc != 0)
+    {
+      seterror(grouped[r].message);
+      return grouped[r].rc;
+    }
+  }
+  // phase 2: exchange, filter, lists to page-locked host memory
+  std::vector<vsa_stats> st(world);
+  m->crew.run([&](uint32_t r) {
+    DeviceOut &o = filtered[r];
+    vsa_result *res = nullptr;
+    pipelinefilter(m, r, bits[r], info.totallength, nrows, o, &res);
+    if (o.rc != 0 || res == nullptr)
+    {
+      if (o.rc == 0)
+      {
+        (void) fail(o, -100, "vsa_multi: range filter gave no list");
+      }
+      return;
+    }
+    const uint64_t c = vsa_result_count(res);
+    if (c > p->hostcap[r])
+    {
+      if (p->hostlist[r] != nullptr)
+      {
+        (void) hipHostFree(p->hostlist[r]);
+        p->hostlist[r] = nullptr;
+      }
+      p->hostcap[r] = c + c / 8 + 1024;
+      if (hipHostMalloc((void **) &p->hostlist[r],
+                        p->hostcap[r] * sizeof(vsa_match),
+                        hipHostMallocDefault) != hipSuccess)
+      {
+        p->hostcap[r] = 0;
+        (void) fail(o, -100, "vsa_multi: no page-locked memory for the list");
+      }
+    }
+    if (o.rc == 0 && c > 0 && vsa_result_fetch(res, p->hostlist[r], c) != 0)
+    {
+      (void) fail(o, -100, nullptr);
+    }
+    if (o.rc == 0)
+    {
+      lists[r] = p->hostlist[r];
+      counts[r] = c;
+    }
+    vsa_result_free(res);
+  });
+  for (uint32_t r = 0; r < world; r++)
+  {
+    if (filtered[r].rc != 0)
+    {
+      seterror(filtered[r].message);
+      return filtered[r].rc;
+    }
+    st[r] = filtered[r].stats;
+    st[r].candidates = nrows[r];
+  }
+  return reducecounters(m, st, total);
+}

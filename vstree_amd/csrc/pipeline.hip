@@ -711,6 +711,63 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
   return out;
 }
 
+// ---- for a caller that runs one pipeline per GPU (multi_gpu.cpp) ----------
+
+// the number the first query of the NEXT submitted batch gets (a job whose
+// batches are dealt out to several pipelines numbers its queries itself)
+extern "C" int vsa_pipeline_set_offset(vsa_pipeline *p, uint64_t firstquery)
+{
+  if (p == nullptr)
+  {
+    VSA_ERROR("vsa_pipeline_set_offset: NULL argument");
+    return -1;
+  }
+  p->submitted = firstquery;
+  return 0;
+}
+
+// -mum pipelines: the candidate rows of all batches since the last job, where
+// they lie in device memory (16 bytes each: sort key, value; valid until the
+// next batch is submitted), instead of vsa_pipeline_finish -- the caller
+// filters them together with the rows of other GPUs.  Ends the job.
+extern "C" int vsa_pipeline_take_candidates(vsa_pipeline *p,
+                                            const void **device_rows,
+                                            uint64_t *nrows,
+                                            uint32_t *lengthbits)
+{
+  if (p == nullptr || device_rows == nullptr || nrows == nullptr ||
+      lengthbits == nullptr || p->mode != 3)
+  {
+    VSA_ERROR("vsa_pipeline_take_candidates: bad argument (a -mum "
+              "pipeline?)");
+    return -1;
+  }
+  *device_rows = nullptr;
+  *nrows = 0;
+  *lengthbits = p->lengthbits;
+  std::lock_guard<std::mutex> g(p->lock);
+  if (!p->inorder.empty())
+  {
+    VSA_ERROR("vsa_pipeline_take_candidates: batches are still outstanding");
+    return -1;
+  }
+  if (p->failed != 0)
+  {
+    const int frc = p->failed;
+    VSA_ERROR("a batch of the job failed: %s", p->failure.c_str());
+    p->failed = 0;
+    p->failure.clear();
+    p->nrows = 0;
+    p->candidates = 0;
+    return frc;
+  }
+  *device_rows = p->rows;
+  *nrows = p->nrows;
+  p->nrows = 0; // the next job starts afresh
+  p->candidates = 0;
+  return 0;
+}
+
 extern "C" void vsa_pipeline_close(vsa_pipeline *p)
 {
   if (p == nullptr)

@@ -27,6 +27,13 @@ SIGNATURES = {
     "vsa_multi_free_matches": (None, [_V]),
     "vsa_multi_findmatches_device": (_I, [_V, _I, _U64, _PP, _PP,
                                           C.POINTER(V.Stats)]),
+    "vsa_multi_pipeline_open": (_I, [_V, _I, _U64, _U32, _U64, _U64, _PP]),
+    "vsa_multi_pipeline_hostrows": (_I, [_V, _PP, _PP]),
+    "vsa_multi_pipeline_submit": (_I, [_V, _U64, _U64]),
+    "vsa_multi_pipeline_next": (_I, [_V, _PP, C.POINTER(_U64)]),
+    "vsa_multi_pipeline_finish": (_I, [_V, _PP, C.POINTER(_U64),
+                                       C.POINTER(V.Stats)]),
+    "vsa_multi_pipeline_close": (None, [_V]),
     "vsa_multi_findmatches_cb": (_I, [_V, _I, _U64, _V, _U64, _V, _V, _U64,
                                       V.PROCESSMATCH, _V]),
     "vsa_multi_findapproxcompletematches": (
@@ -162,6 +169,92 @@ class Multi:
     def close(self):
         if self._h and lib is not None:
             lib.vsa_multi_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class MultiPipeline:
+    """vsa_multi_pipeline_*: a packed pipeline per replica, the batches of a
+    job dealt out in turn and delivered in submission order"""
+
+    def __init__(self, multi, mode, searchlength, querylength, maxqueries,
+                 maxspecial=None):
+        self._h = None
+        h = C.c_void_p()
+        self.maxspecial = int(maxqueries if maxspecial is None
+                              else maxspecial)
+        V._check(lib.vsa_multi_pipeline_open(
+            multi._h, int(mode), int(searchlength), int(querylength),
+            int(maxqueries), self.maxspecial, C.byref(h)))
+        self._h, self._multi = h, multi
+        self.m, self.maxqueries = int(querylength), int(maxqueries)
+        self.W = int(V.lib.vsa_packed_words(self.m))
+        self.n = multi.ndevices()
+
+    def hostrows(self):
+        r, sp = C.c_void_p(), C.c_void_p()
+        rc = lib.vsa_multi_pipeline_hostrows(self._h, C.byref(r), C.byref(sp))
+        if rc == 1:
+            return None
+        V._check(rc)
+        rows = np.ctypeslib.as_array(
+            (C.c_uint64 * (self.W * self.maxqueries)).from_address(r.value))
+        special = np.ctypeslib.as_array(
+            (C.c_uint8 * max(1, self.m * self.maxspecial)).from_address(
+                sp.value))
+        return rows, special
+
+    def submit(self, nq, nspecial):
+        V._check(lib.vsa_multi_pipeline_submit(self._h, int(nq),
+                                               int(nspecial)))
+
+    def pack_into_slot(self, symbols, nq, stride=None):
+        got = self.hostrows()
+        if got is None:
+            return False
+        rows, special = got
+        ns = C.c_uint64(0)
+        symbols = np.ascontiguousarray(symbols, np.uint8)
+        V._check(V.lib.vsa_pack_reads(
+            V._ptr(symbols), nq, self.m,
+            self.m if stride is None else stride, V._ptr(rows),
+            V._ptr(special), self.maxspecial, C.byref(ns)))
+        self.submit(nq, ns.value)
+        return True
+
+    def next(self, copy=True):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        rc = lib.vsa_multi_pipeline_next(self._h, C.byref(ptr), C.byref(n))
+        if rc == 1 or n.value == 0:
+            return rc, np.zeros(0, MATCH_DTYPE)
+        a = np.ctypeslib.as_array(
+            (C.c_uint64 * (4 * n.value)).from_address(ptr.value)).view(
+                MATCH_DTYPE)
+        return rc, a.copy() if copy else a
+
+    def finish(self, copy=True):
+        """-mum: ([list of replica r], Stats of the job)"""
+        ptrs = (C.c_void_p * self.n)()
+        cnts = (C.c_uint64 * self.n)()
+        st = V.Stats()
+        V._check(lib.vsa_multi_pipeline_finish(self._h, ptrs, cnts,
+                                               C.byref(st)))
+        out = []
+        for r in range(self.n):
+            if cnts[r] == 0:
+                out.append(np.zeros(0, MATCH_DTYPE))
+                continue
+            a = np.ctypeslib.as_array(
+                (C.c_uint64 * (4 * cnts[r])).from_address(ptrs[r])).view(
+                    MATCH_DTYPE)
+            out.append(a.copy() if copy else a)
+        return out, st
+
+    def close(self):
+        if self._h and lib is not None:
+            lib.vsa_multi_pipeline_close(self._h)
             self._h = None
 
     def __del__(self):
