@@ -11,7 +11,7 @@ numbers of the .prj file).
 The 64-bit files are the reference's own (LP64 build).  The md5 sums under
 "md5_32" are those of the same tables narrowed to 32-bit integers (suf, bck,
 llv, skp; integersize=32 in the .prj) -- what `integersize=32` of vsa_mkvtree
-must write, derived here from the reference's output, not from ours."""
+must write (.sds and .ssp hold Uint values, too), derived here from the reference's output, not from ours."""
 import hashlib
 import json
 import os
@@ -29,7 +29,7 @@ import helpers as H  # noqa: E402
 
 FILES = ("prj", "al1", "tis", "ois", "des", "sds", "ssp", "suf", "lcp", "llv",
          "bck", "bwt", "sti1", "skp")
-WIDE = ("suf", "bck", "llv", "skp")
+WIDE = ("suf", "bck", "llv", "skp", "sds", "ssp")
 
 
 def md5file(p, narrow=False):

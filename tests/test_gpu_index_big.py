@@ -16,7 +16,7 @@ import pytest
 import helpers as H
 
 pytestmark = pytest.mark.gpu
-WIDE = ("suf", "bck", "llv", "skp")
+WIDE = ("suf", "bck", "llv", "skp", "sds", "ssp")
 
 
 def md5file(p):
