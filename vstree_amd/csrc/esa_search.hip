@@ -1885,7 +1885,18 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     D = ix->pl;
   }
+  // VSA_DEEP_RECORD=1 (round 4): 64-byte records -- bounds + the bucket's
+  // first seven entries -- for one symbol less of deep prefix: the same bytes
+  // as 16-byte slots one symbol deeper, and a bucket of two to seven suffixes
+  // costs no second line of HBM (profiles/r04/README.md)
+  const char *recenv = getenv("VSA_DEEP_RECORD");
+  const bool records = recenv != nullptr && strcmp(recenv, "1") == 0;
+  const uint32_t slotwords = records ? 8 : 2;
   const char *fd = getenv("VSA_DEEP_PREFIX");
+  if (records && D > ix->pl)
+  {
+    D--;
+  }
   if (fd != nullptr && atoi(fd) >= (int) ix->pl && atoi(fd) <= 16)
   {
     D = (uint32_t) atoi(fd);
@@ -1902,7 +1913,7 @@ int vsa_index_make_esa8(vsa_index *ix)
            hipMemGetInfo(&freeb, &totalb) == hipSuccess)
     {
       const uint64_t codes = 1ull << (2 * D),
-                     need = 16 * codes + 2 * codes * ix->isize +
+                     need = 8 * slotwords * codes + 2 * codes * ix->isize +
                             8 * (ix->n + 1) + ix->n / 4 + totalb / 10;
       if (need <= freeb)
       {
@@ -1927,7 +1938,8 @@ int vsa_index_make_esa8(vsa_index *ix)
   // of the page table on top (profiles/r03/table_read_probe.txt).
   VSA_HIP(hipStreamSynchronize(ix->stream));
   vsa_dev_trim();
-  if (vsa_hip_malloc((void **) &ix->slot16, 2 * ncodes * 8 + 32) != hipSuccess)
+  if (vsa_hip_malloc((void **) &ix->slot16,
+                     (uint64_t) slotwords * ncodes * 8 + 64) != hipSuccess)
   {
     // no room for it (VSA_DEEP_PREFIX asked for more than fits): this index
     // is searched the reference's way
@@ -1999,10 +2011,18 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     const unsigned int grid = (unsigned int) std::min<uint64_t>(
         (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20);
-    if (wide)
+    if (wide && records)
+    {
+      k_make_slots<8, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          (const uint64_t *) ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
+    } else if (wide)
     {
       k_make_slots<2, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
           (const uint64_t *) ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
+    } else if (records)
+    {
+      k_make_slots<8, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
+          ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
     } else
     {
       k_make_slots<2, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
@@ -2014,8 +2034,9 @@ int vsa_index_make_esa8(vsa_index *ix)
     VSA_HIP(hipStreamSynchronize(ix->stream));
     (void) hipFree(ix->bck2);
     ix->bck2 = nullptr;
-    ix->slotwords = 2;
-    ix->device_bytes += 2 * ncodes * 8 - 2 * ncodes * ix->isize;
+    ix->slotwords = slotwords;
+    ix->device_bytes += (uint64_t) slotwords * ncodes * 8 -
+                        2 * ncodes * ix->isize;
   }
   (void) hipFree(dtoobig);
   if (wide && htoobig != 0)
