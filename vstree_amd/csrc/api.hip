@@ -552,6 +552,7 @@ extern "C" void vsa_index_close(vsa_index *ix)
   (void) hipFree(ix->tis2);
   (void) hipFree(ix->spec64);
   (void) hipFree(ix->isa32);
+  (void) hipFree(ix->repbits);
   if (ix->stream != nullptr)
   {
     vsa_dev_forget_stream(ix->stream);

@@ -1031,9 +1031,6 @@ struct DeepFront
 {
   uint64_t left;             // first suffix of the bucket
   uint64_t first;            // esa8[left] from the slot (0: empty bucket)
-  const uint64_t *more;      // where the entries behind the first one lie:
-                             // in the bucket's record (64-byte records) or
-                             // in esa8
   uint32_t cnt, qkey, limit; // suffixes in the bucket; key symbols, how
                              // many of them the query has
   int state;                 // VSA_LOC_NONE / FOUND (= go on) / SLOW
@@ -1051,7 +1048,6 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, QP query,
   f.left = 0;
   f.cnt = f.qkey = f.limit = 0;
   f.first = 0;
-  f.more = ix.esa8;
   if (active)
   {
     uint32_t valid = 32; // leading regular symbols inside the query
@@ -1110,13 +1106,9 @@ vsa_deep_front(const DevIndex<IDX> &ix, bool active, QP query,
       }
       // (left, mid) of the deep bucket with the bucket's first entry: one
       // 16-byte load (deep tables always come with the fused slot table)
-      const uint64_t *slot = ix.slot16 + (uint64_t) ix.slotwords * code;
-      const vsa_u128 sl = vsa_load16(slot);
+      const vsa_u128 sl = vsa_load16(ix.slot16 + 2 * code);
       f.first = sl.hi;
       vsa_slotbounds<IDX>(sl.lo, f.left, f.cnt);
-      // 64-byte records (slotwords 8): the bucket's first seven entries lie
-      // behind its bounds, in the 128-byte line HBM has just delivered
-      f.more = ix.slotwords == 8 ? slot + 2 : ix.esa8 + f.left + 1;
       f.state = (f.cnt > 0) ? VSA_LOC_FOUND : VSA_LOC_NONE;
     }
   }
@@ -1196,86 +1188,67 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f, QP query,
   // only the first `limit` key symbols of the query exist
   const uint32_t qk = qkey >> (2 * (VSA_KEYSYMS - limit));
 
-  // Small buckets (nearly all of them: up to four suffixes with 16-byte
-  // slots, whose deep prefix is chosen so that a bucket holds about one; up
-  // to seven with 64-byte records) are looked at entry by entry.  The first
-  // entry came with the bounds; the others come two per 16-byte load, only
-  // the loads the bucket's size asks for (a divergent load costs its CU's
-  // address unit about a cycle per lane whatever its width).  With records
-  // they lie in the 128-byte line the first load has brought: no second line
-  // of HBM for a bucket of two to seven.  The entry BEHIND a bucket belongs
-  // to another bucket and shares fewer than D symbols with this one: its lcp
-  // byte is below every length it is ever compared with (D <= the least
-  // length), so it stands as 0 and is not fetched.
-  const uint32_t smallmax = ix.slotwords == 8 ? 7u : 4u;
-  const bool small = searching && cnt <= smallmax;
+  // Buckets of up to four suffixes (nearly all of them: the deep prefix is
+  // chosen so that a bucket holds about one) are fetched whole, together
+  // with the entry behind them, in one round trip: five independent loads.
+  const bool small = searching && cnt <= 4;
   const uint32_t ksh = 2 * (VSA_KEYSYMS - limit);
+  uint64_t e[5] = {0, 0, 0, 0, 0};
+  if (small && cnt == 1)
+  {
+    // the whole bucket came with the bounds.  The entry behind it belongs to
+    // another bucket and shares fewer than D symbols with it, so its lcp byte
+    // (0 here) is below every match length either way: nothing else is needed.
+    e[0] = first;
+  } else if (small)
+  {
+    // the first entry came with the bounds: entries 1, 2 in one load, and 3, 4
+    // in a second one for the buckets that have them (a divergent load costs
+    // its CU's address unit about a cycle per lane whatever its width, and a
+    // bucket of two -- the usual case here -- needs one instead of three)
+    // (esa8 has eight entries of slack behind index n)
+    const uint64_t *p = ix.esa8 + (uint64_t) dl + 1;
+    const vsa_u128 e12 = vsa_load16(p);
+    e[0] = first;
+    e[1] = e12.lo;
+    e[2] = e12.hi;
+    if (cnt > 2)
+    {
+      const vsa_u128 e34 = vsa_load16(p + 2);
+      e[3] = e34.lo;
+      e[4] = e34.hi;
+    }
+  }
   // lower bound on keys: lo = number of bucket entries whose key is smaller
-  // than the query's; pred = entry lo-1, succ = entry lo, next = entry lo+1
+  // than the query's
   uint32_t lo = 0;
   bool flagged = false;
   // qleft: is there a member of the bucket that shares enough symbols with
   // the query to be reported, and do all such members have qleft in front?
   bool anylong = false, allnotleft = true;
   const uint32_t enough = needleft < D + limit ? needleft : D + limit;
-  uint64_t epred = 0, esucc = 0, enext = 0;
   if (small)
   {
-    const vsa_u128 zero = {0, 0};
-    const uint64_t *p = f.more;
-    const vsa_u128 e12 = cnt >= 2 ? vsa_load16(p) : zero,
-                   e34 = cnt >= 4 ? vsa_load16(p + 2) : zero,
-                   e56 = cnt >= 6 ? vsa_load16(p + 4) : zero;
-    bool got = false, gotnext = false;
-    // (keys ascend inside a bucket -- entries with a special symbol in the
-    // key window raise `flagged`, and the lane takes the reference walk)
-    auto visit = [&](uint32_t i, uint64_t ei) __attribute__((always_inline)) {
-      const bool member = i < cnt;
-      const uint64_t en = member ? ei : 0;
-      const uint32_t tk =
-          ((uint32_t) (en >> VSA_KEYSHIFT) & VSA_KEYMASK) >> ksh;
-      const bool smaller = member && tk < qk;
-      if (member)
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+    {
+      if (i < cnt)
       {
-        flagged = flagged || (en & VSA_KEYFLAG) != 0;
+        flagged = flagged || (e[i] & VSA_KEYFLAG) != 0;
+        const uint32_t tk =
+            ((uint32_t) (e[i] >> VSA_KEYSHIFT) & VSA_KEYMASK) >> ksh;
+        lo += (tk < qk) ? 1u : 0u;
         if (qleft < 0x100u)
         {
           const bool islong = D + vsa_keylcp(tk, qk, limit) >= enough;
           const bool sameleft =
-              (en & VSA_LEFTSPECIAL) == 0 &&
-              (uint32_t) ((en >> VSA_LEFTSHIFT) & 3u) == qleft;
+              (e[i] & VSA_LEFTSPECIAL) == 0 &&
+              (uint32_t) ((e[i] >> VSA_LEFTSHIFT) & 3u) == qleft;
           anylong = anylong || islong;
           allnotleft = allnotleft && (!islong || sameleft);
         }
       }
-      if (i <= cnt)
-      {
-        if (!got)
-        {
-          if (smaller)
-          {
-            lo++;
-            epred = en;
-          } else
-          {
-            esucc = en;
-            got = true;
-          }
-        } else if (!gotnext)
-        {
-          enext = en;
-          gotnext = true;
-        }
-      }
-    };
-    visit(0, first);
-    visit(1, e12.lo);
-    visit(2, e12.hi);
-    visit(3, e34.lo);
-    visit(4, e34.hi);
-    visit(5, e56.lo);
-    visit(6, e56.hi);
-    visit(7, 0);
+    }
   }
   // larger buckets: binary search; trip count = that of the largest such
   // bucket in the wavefront, so the lanes stay converged
@@ -1312,13 +1285,22 @@ vsa_locate_deep_from(const DevIndex<IDX> &ix, const DeepFront &f, QP query,
   // for the size of a tie.  They are taken by suffix-array index whether or
   // not they lie in the bucket: their lcp bytes serve the uniqueness test of
   // the located suffix.
+  uint64_t epred = 0, esucc = 0, enext = 0;
   bool haspred = false, hassucc = false, hasnext = false;
   if (searching)
   {
     haspred = lo > 0;
     hassucc = lo < cnt;
     hasnext = lo + 1 < cnt;
-    if (!small)
+    if (small)
+    {
+      // lo <= cnt <= 4: everything is in e[0..4]
+      epred = lo == 1 ? e[0] : (lo == 2 ? e[1] : (lo == 3 ? e[2] : e[3]));
+      esucc = lo == 0 ? e[0]
+                      : (lo == 1 ? e[1]
+                                 : (lo == 2 ? e[2] : (lo == 3 ? e[3] : e[4])));
+      enext = lo == 0 ? e[1] : (lo == 1 ? e[2] : (lo == 2 ? e[3] : e[4]));
+    } else
     {
       const uint64_t base = (uint64_t) dl + lo;
       if (base > 0)

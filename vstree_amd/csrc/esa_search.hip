@@ -51,6 +51,7 @@
 #include "search_complete.inc"
 #include "search_query.inc"
 #include "mum_workplan.inc"
+#include "mem_workplan.inc"
 #include "mum_filter.inc"
 #include "selfmum_scan.inc"
 
@@ -1105,6 +1106,99 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     }
     qs = devqueries(queries);
   }
+  // MEM (-l L): first pass, then the plan of mem_workplan.inc -- aligned
+  // stretches answered from one bit per text position, the rest searched
+  const bool memplan = !domum && deepok && queries->rows == nullptr &&
+                       searchlength <= 255 && maxoffsets > 1 &&
+                       maxoffsets < 0xFFFFu && queries->nq < 0xFFFFFFFFull &&
+                       (index->tune & 2u) == 0;
+  if (memplan)
+  {
+    const uint64_t nq = queries->nq;
+    // one bit per text position: does its suffix have a neighbour in the
+    // suffix array with lcp >= L?  Made once per (index, L), kept.
+    if (index->repbits == nullptr || index->repleast != searchlength)
+    {
+      if (index->repbits == nullptr)
+      {
+        VSA_HIP(vsa_hip_malloc((void **) &index->repbits,
+                               ((index->n + 1) / 32 + 4) * 4));
+      }
+      VSA_HIP(hipMemsetAsync(index->repbits, 0, ((index->n + 1) / 32 + 4) * 4,
+                             stream));
+      k_repeat_bits<IDX><<<vsa_grid(blocksfor((index->n + 16) / 16)),
+                           VSA_BLOCK, 0, stream>>>(
+          ix.lcp, ix.suf, index->n, searchlength, index->repbits);
+      VSA_HIP(hipGetLastError());
+      index->repleast = searchlength;
+    }
+    if (wcount.alloc((nq + 1) * 4) || wfirste.alloc(nq * 4) ||
+        wfmlen.alloc(nq * 4) || wfmdb.alloc(nq * 8) ||
+        wplan.alloc(nq * sizeof(PlanRanges)))
+    {
+      return -100;
+    }
+    tfirst.start();
+    {
+      const bool staged = qs.dense != 0 && qs.uniformlen <= 128 &&
+                          (qs.uniformlen & 3u) == 0;
+      if (staged)
+      {
+        k_mum_first<IDX, true, true>
+            <<<gridfor(nq), VSA_BLOCK, (size_t) VSA_BLOCK * qs.uniformlen,
+               stream>>>(ix, qs, perquery, searchlength,
+                         wcount.as<uint32_t>(), wfirste.as<uint32_t>(),
+                         wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>());
+      } else
+      {
+        k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+            ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+            wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+            wfmdb.as<uint64_t>());
+      }
+    }
+    tfirst.stop();
+    VSA_HIP(hipGetLastError());
+    {
+      // room for every answer of the workgroups that share a region (a read
+      // answers at most one offset per round)
+      const uint64_t nb = blocksfor(nq),
+                     pershard = (nb + nshards - 1) / nshards;
+      pcap = pershard * VSA_BLOCK * VSA_PLAN_ROUNDS;
+      if (pcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
+          pdoff.alloc(nshards * 8) || psummary.alloc(4 * 8) ||
+          prawout.alloc(nshards * pcap * recsize) ||
+          prawkeys.alloc(nshards * pcap * 8))
+      {
+        return -100;
+      }
+      VSA_HIP(hipMemsetAsync(pcursor.p, 0,
+                             (size_t) nshards * VSA_CURSOR_STRIDE * 8,
+                             stream));
+      PlanEmit em;
+      em.base = dbase;
+      em.perquery = perquery;
+      em.out = prawout.as<vsa_match>();
+      em.outkey = prawkeys.as<uint64_t>();
+      em.shardcap = pcap;
+      em.shardmask = nshards - 1;
+      em.cursors = pcursor.as<unsigned long long>();
+      em.packbits = 0;
+      em.valbits = 0;
+      k_mem_plan<IDX><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+          ix, qs, perquery, searchlength, wfirste.as<uint32_t>(),
+          wfmdb.as<uint64_t>(), index->repbits, wcount.as<uint32_t>(),
+          wplan.as<PlanRanges>(), em);
+      VSA_HIP(hipGetLastError());
+      k_shard_summary<<<1, 1024, 0, stream>>>(
+          pcursor.as<unsigned long long>(), nshards, pdoff.as<uint64_t>(),
+          nullptr, nullptr, psummary.as<uint64_t>());
+      VSA_HIP(hipGetLastError());
+    }
+    planemit = true;
+    fromplan = true;
+    plansearches = nq; // (an upper bound of the plan's own locates per round)
+  }
   if (reduce)
   {
     const uint64_t nq = queries->nq;
@@ -1331,7 +1425,16 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           ix, qs, dbase, perquery, nwork, searchlength,                       \
           rawout.as<vsa_match>(), rawkeys.as<uint64_t>(), shardcap,           \
           nshards - 1, cursor.as<unsigned long long>(), packbits, valbits)
-    if (fromplan && rows && (rowbits & 4))
+    if (fromplan && memplan)
+    {
+      k_query_search_planned<IDX, 256, true, false, false>
+          <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
+              ix, qs, dbase, perquery, wplan.as<PlanRanges>(),
+              wcount.as<uint32_t>(), searchlength, rawout.as<vsa_match>(),
+              rawkeys.as<uint64_t>(), shardcap, nshards - 1,
+              cursor.as<unsigned long long>(), packbits, valbits,
+              blocksum.as<unsigned long long>());
+    } else if (fromplan && rows && (rowbits & 4))
     {
       k_query_search_planned<IDX, 256, true, true>
           <<<vsa_grid(nplanblocks), 256, 0, stream>>>(
@@ -1885,18 +1988,7 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     D = ix->pl;
   }
-  // VSA_DEEP_RECORD=1 (round 4): 64-byte records -- bounds + the bucket's
-  // first seven entries -- for one symbol less of deep prefix: the same bytes
-  // as 16-byte slots one symbol deeper, and a bucket of two to seven suffixes
-  // costs no second line of HBM (profiles/r04/README.md)
-  const char *recenv = getenv("VSA_DEEP_RECORD");
-  const bool records = recenv != nullptr && strcmp(recenv, "1") == 0;
-  const uint32_t slotwords = records ? 8 : 2;
   const char *fd = getenv("VSA_DEEP_PREFIX");
-  if (records && D > ix->pl)
-  {
-    D--;
-  }
   if (fd != nullptr && atoi(fd) >= (int) ix->pl && atoi(fd) <= 16)
   {
     D = (uint32_t) atoi(fd);
@@ -1913,7 +2005,7 @@ int vsa_index_make_esa8(vsa_index *ix)
            hipMemGetInfo(&freeb, &totalb) == hipSuccess)
     {
       const uint64_t codes = 1ull << (2 * D),
-                     need = 8 * slotwords * codes + 2 * codes * ix->isize +
+                     need = 16 * codes + 2 * codes * ix->isize +
                             8 * (ix->n + 1) + ix->n / 4 + totalb / 10;
       if (need <= freeb)
       {
@@ -1938,8 +2030,7 @@ int vsa_index_make_esa8(vsa_index *ix)
   // of the page table on top (profiles/r03/table_read_probe.txt).
   VSA_HIP(hipStreamSynchronize(ix->stream));
   vsa_dev_trim();
-  if (vsa_hip_malloc((void **) &ix->slot16,
-                     (uint64_t) slotwords * ncodes * 8 + 64) != hipSuccess)
+  if (vsa_hip_malloc((void **) &ix->slot16, 2 * ncodes * 8 + 32) != hipSuccess)
   {
     // no room for it (VSA_DEEP_PREFIX asked for more than fits): this index
     // is searched the reference's way
@@ -2011,18 +2102,10 @@ int vsa_index_make_esa8(vsa_index *ix)
   {
     const unsigned int grid = (unsigned int) std::min<uint64_t>(
         (ncodes + VSA_BLOCK - 1) / VSA_BLOCK, 1u << 20);
-    if (wide && records)
-    {
-      k_make_slots<8, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-          (const uint64_t *) ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
-    } else if (wide)
+    if (wide)
     {
       k_make_slots<2, uint64_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
           (const uint64_t *) ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
-    } else if (records)
-    {
-      k_make_slots<8, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
-          ix->bck2, ix->esa8, ncodes, ix->slot16, dtoobig);
     } else
     {
       k_make_slots<2, uint32_t><<<grid, VSA_BLOCK, 0, ix->stream>>>(
@@ -2034,9 +2117,8 @@ int vsa_index_make_esa8(vsa_index *ix)
     VSA_HIP(hipStreamSynchronize(ix->stream));
     (void) hipFree(ix->bck2);
     ix->bck2 = nullptr;
-    ix->slotwords = slotwords;
-    ix->device_bytes += (uint64_t) slotwords * ncodes * 8 -
-                        2 * ncodes * ix->isize;
+    ix->slotwords = 2;
+    ix->device_bytes += 2 * ncodes * 8 - 2 * ncodes * ix->isize;
   }
   (void) hipFree(dtoobig);
   if (wide && htoobig != 0)

@@ -121,6 +121,11 @@ struct vsa_index
   // inverse suffix array, isa32[suf[i]] = i: made by the first call that wants
   // it (tandem repeats, selfmatch_search.inc) and kept; nullptr before
   mutable uint32_t *isa32;
+  // one bit per text position: its suffix has a suffix-array neighbour with
+  // lcp >= repleast (mem_workplan.inc); made by the first MEM batch that
+  // asks for this least length and kept; nullptr before
+  mutable uint32_t *repbits = nullptr;
+  mutable uint32_t repleast = 0;
 
   template <typename IDX>
   DevIndex<IDX> view() const
