@@ -388,8 +388,15 @@ int vsa_findmumcandidates_grouped(const vsa_index *index,
   findapproxcompletematchesindex (Vmengine/approxcompl.c:138-199) ->
   splitesaapm (Vmengine/splitesaapm.c:458-558).
     doedist   1: edit distance (-e), 0: Hamming distance (-h)
-    distvalue K;  percent != 0: the threshold is m*K/100 (-e Kp, -h Kp,
-              Vmengine/initcompl.c:52-56)
+    distvalue K;  percent 1: the threshold is m*K/100 (-e Kp, -h Kp,
+              Vmengine/initcompl.c:52-56); percent 2: "best of" (-e Kb, -h Kb,
+              initcompl.c:59-77) -- read by read (Vmengine/fcomplete.c:251-252
+              restores K in front of every read) the smallest threshold
+              t <= m*K/100 at which the read has a match at all
+              (Vmengine/approxcompl.c:80-122), then the read's matches at
+              threshold t; a read without one reports nothing.  Two passes
+              here: the smallest distance of every read from a run at the
+              percent thresholds, then every read at exactly its own
   A match is (length, dbstart, queryseq, distance): length = Match.length1
   (for -e the best-distance, then longest prefix behind dbstart,
   Vmengine/longestmatch.c; for -h the query length), the distance travels in

@@ -308,6 +308,15 @@ static int getgpumulti(Virtualtree *virtualtree, const int *devices,
   return 0;
 }
 
+/* Matchparam.maxdist.distinterpretation (qualint.h) -> the `percent` argument
+   of vsa_findapproxcompletematches: 0 K, 1 Kp, 2 Kb */
+static int thresholdkind(const Matchparam *matchparam)
+{
+  return matchparam->maxdist.distinterpretation == Qualpercentaway
+             ? 1
+             : (matchparam->maxdist.distinterpretation == Qualbestof ? 2 : 0);
+}
+
 /* one exact engine call on all replicas; the matches go to `sink` */
 static int runonallgpus(Virtualtree *virtualtree, Multiseq *queries,
                         BOOL rcmode, int mode, Uint searchlength,
@@ -410,10 +419,9 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
 
   const int approx = !MPARMEXACTMATCH(&matchparam->maxdist);
 
-  /* approximate matching: -e K / -h K and the percent forms (qualint.h:12-13)
-     go to the GPU; "best of" (Qualbestof, initcompl.c:59-77) stays here */
+  /* approximate matching: -e K / -h K, the percent forms and "best of"
+     (qualint.h:7-13, initcompl.c:52-77) go to the GPU */
   if (!usegpu() || online ||
-      (approx && matchparam->maxdist.distinterpretation == Qualbestof) ||
       cpridxpatsearchbundle->handle != NULL || virtualtree->suftab == NULL ||
       virtualtree->bcktab == NULL || virtualtree->lcptab == NULL)
   {
@@ -453,7 +461,7 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
       rc = vsa_multi_findapproxcompletematches_cb(
           multi, MPARMEDISTMATCH(&matchparam->maxdist) ? 1 : 0,
           (uint64_t) matchparam->maxdist.distvalue,
-          matchparam->maxdist.distinterpretation == Qualpercentaway ? 1 : 0,
+          thresholdkind(matchparam),
           rcmode ? qseq->rcsequence : qseq->sequence, qseq->totallength,
           start, length, qseq->numofsequences, approxsink, &sink);
       free(start);
@@ -510,7 +518,7 @@ Sint __wrap_findcompletematches(Virtualtree *virtualtree,
     rc = vsa_findapproxcompletematches_cb(
         index, queries, MPARMEDISTMATCH(&matchparam->maxdist) ? 1 : 0,
         (uint64_t) matchparam->maxdist.distvalue,
-        matchparam->maxdist.distinterpretation == Qualpercentaway ? 1 : 0,
+        thresholdkind(matchparam),
         approxsink, &sink);
     if (rc == VSA_NOT_COVERED)
     {

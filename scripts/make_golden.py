@@ -251,6 +251,10 @@ def main():
                                "genome.fna"], wd, approx=True)
     record(case, "approx_h2", ["-complete", "-h", "2", "-q", "queries.fna",
                                "genome.fna"], wd, approx=True)
+    record(case, "approx_e5b", ["-complete", "-e", "5b", "-q", "queries.fna",
+                                "genome.fna"], wd, approx=True)
+    record(case, "approx_h5b", ["-complete", "-h", "5b", "-q", "queries.fna",
+                                "genome.fna"], wd, approx=True)
     shutil.rmtree(wd)
 
     # ---- 6. C5 in small: 150 bp (and some 100 bp) reads with up to 3 edit
@@ -305,6 +309,12 @@ def main():
     record(case, "approx_h2", ["-complete", "-h", "2", "-q", "reads.fna",
                                "db.fna"], wd, approx=True)
     record(case, "approx_e2p", ["-complete", "-e", "2p", "-q", "reads.fna",
+                                "db.fna"], wd, approx=True)
+    # "best of" thresholds (Vmengine/initcompl.c:59-77): every read at the
+    # smallest threshold <= K percent of its length at which it has a match
+    record(case, "approx_e4b", ["-complete", "-e", "4b", "-q", "reads.fna",
+                                "db.fna"], wd, approx=True)
+    record(case, "approx_h3b", ["-complete", "-h", "3b", "-q", "reads.fna",
                                 "db.fna"], wd, approx=True)
     record(case, "complete", ["-complete", "-q", "reads.fna", "db.fna"], wd)
     record(case, "supermax20", ["-supermax", "-l", "20", "db.fna"], wd)

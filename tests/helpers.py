@@ -308,7 +308,10 @@ class OracleNotCovered(OracleError):
 
 def oracle_approx(index, queries, doedist, distvalue, percent=False):
     """vmatch -complete -e K | -h K: matches carry the distance in
-    querystart"""
+    querystart.  percent: False / 0 absolute, True / 1 percent of the read's
+    length (Kp), 2 "best of" (Kb)"""
+    if int(percent) == 2:
+        return _oracle_approx_bestof(index, queries, doedist, distvalue)
     lib = oracle_lib()
     out, err = OrcMatches(), C.create_string_buffer(512)
     lib.orc_matches_init(C.byref(out))
@@ -323,6 +326,31 @@ def oracle_approx(index, queries, doedist, distvalue, percent=False):
         e.partial = res
         raise e
     return res
+
+
+def _oracle_approx_bestof(index, queries, doedist, distvalue):
+    """-e Kb / -h Kb (Vmengine/initcompl.c:59-77, approxcompl.c:80-122;
+    fcomplete.c:251-252 restores K in front of every read): every read at the
+    smallest threshold t <= m K / 100 at which it has a match; reads without
+    one report nothing.  The existence check of the reference is monotone in
+    t, so t = the read's smallest distance within m K / 100."""
+    first = oracle_approx(index, queries, doedist, distvalue, percent=1)
+    best = np.full(queries.nq, -1, np.int64)
+    for qi, d in zip(first["queryseq"], first["querystart"]):
+        if best[qi] < 0 or d < best[qi]:
+            best[qi] = d
+    parts = []
+    for t in sorted(set(int(b) for b in best if b >= 0)):
+        which = np.flatnonzero(best == t)
+        sub = Queries(queries.symbols, queries.start[which],
+                      queries.length[which])
+        m = oracle_approx(index, sub, doedist, t).copy()
+        m["queryseq"] = which[m["queryseq"]]
+        parts.append(m)
+    if not parts:
+        return first[:0]
+    allm = np.concatenate(parts)
+    return allm[np.argsort(allm["queryseq"], kind="stable")]
 
 
 def selfmum_scan_range(index, searchlength, first=2, last=None):

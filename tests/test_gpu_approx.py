@@ -17,8 +17,11 @@ APPROX = [(c, k) for c in sorted(M) for k in sorted(M[c]["runs"])
 
 
 def spec(key):
+    """approx_e2 / approx_h2p / approx_e5b -> (edit distance?, K, 0 absolute |
+    1 percent | 2 best of)"""
     s = key[len("approx_"):]
-    return s[0] == "e", int(s[1:].rstrip("p")), s.endswith("p")
+    return s[0] == "e", int(s[1:].rstrip("pb")), \
+        1 if s.endswith("p") else (2 if s.endswith("b") else 0)
 
 
 def without_special_queries(q):
@@ -300,3 +303,53 @@ def test_short_patterns_and_piece_thresholds_equal_the_oracle(V, doedist,
         got = V.findapproxcompletematches(gi, gq, doedist, k).fetch()
         assert len(want) > 20
         assert np.array_equal(got, want), (doedist, seed, k)
+
+
+@pytest.mark.parametrize("doedist", [True, False])
+@pytest.mark.parametrize("seed", range(3))
+def test_best_of_thresholds_equal_the_oracle(V, doedist, seed):
+    """vmatch -complete -e Kb | -h Kb (Vmengine/initcompl.c:59-77): every read
+    at the smallest threshold <= K percent of its length at which it has a
+    match -- reads of several lengths, with 0 .. 6 edit operations, some
+    without a match within the bound, some exact, a text with repeats; lists
+    in the reference's order (the oracle's restatement of best-of is pinned by
+    the golden lists approx_e5b / approx_h5b / approx_e4b / approx_h3b)"""
+    rng = np.random.default_rng(31000 + 10 * seed + int(doedist))
+    unit = rng.integers(0, 4, 500).astype(np.uint8)
+    t = rng.integers(0, 4, 80000).astype(np.uint8)
+    for r in range(10):
+        p = int(rng.integers(0, len(t) - 500))
+        u = unit.copy()
+        for e in range(int(rng.integers(0, 4))):
+            u[int(rng.integers(0, 500))] = rng.integers(0, 4)
+        t[p:p + 500] = u
+    t[40000] = H.SEPARATOR
+    idx = H.oracle_build_index(t, 4)
+    reads = []
+    for i in range(400):
+        m = int(rng.choice([60, 100, 150, 151]))
+        p = int(rng.integers(0, len(t) - m))
+        r = t[p:p + m].copy()
+        r[r >= 254] = 0
+        for e in range(int(rng.integers(0, 7))):
+            x = int(rng.integers(0, len(r)))
+            kind = int(rng.integers(0, 3)) if doedist else 0
+            if kind == 0:
+                r[x] = (r[x] + 1 + rng.integers(0, 3)) & 3
+            elif kind == 1 and len(r) > 40:
+                r = np.delete(r, x)
+            else:
+                r = np.insert(r, x, rng.integers(0, 4))
+        reads.append(r.astype(np.uint8))
+    q = H.Queries.from_list(reads)
+    gi = V.Index.from_tables(idx.n, idx.prefixlength, 4, idx.tis, idx.suf,
+                             idx.lcp, idx.llv, idx.bck, idx.bwt)
+    gq = V.Queries.from_host(q.symbols, q.start, q.length)
+    for k in (5, 3, 1):
+        got = V.findapproxcompletematches(gi, gq, doedist, k, 2).fetch()
+        want = H.oracle_approx(idx, q, doedist, k, percent=2)
+        assert np.array_equal(got, want), (seed, doedist, k)
+        # fewer reads answer than with the percent threshold itself, and none
+        # of them at a larger distance than its best
+        pct = V.findapproxcompletematches(gi, gq, doedist, k, 1).fetch()
+        assert set(got["queryseq"]) == set(pct["queryseq"])

@@ -63,8 +63,8 @@ def test_replicas_answer_approximate_matching(V, MG, world):
             if not key.startswith("approx_"):
                 continue
             spec = key[len("approx_"):]
-            doedist, k, pct = spec[0] == "e", int(spec[1:].rstrip("p")), \
-                spec.endswith("p")
+            doedist, k, pct = spec[0] == "e", int(spec[1:].rstrip("pb")), \
+                1 if spec.endswith("p") else (2 if spec.endswith("b") else 0)
             got, st, rc, msg = m.findapproxcompletematches(
                 q.symbols, q.start, q.length, doedist, k, pct)
             assert rc == 0, (case, key, msg)

@@ -61,14 +61,16 @@ def test_packed_batch_reproduces_the_golden_lists(V, bits):
         assert np.array_equal(got, H.expected("c1", key)), key
         rb = V.findquerymatches(gi, byte, 20, **kw)
         sb, sp = rb.stats(), r.stats()
-        assert (sb.count, sb.sumlength, sb.searches, sb.candidates) == \
-            (sp.count, sp.sumlength, sp.searches, sp.candidates), key
+        assert (sb.count, sb.sumlength, sb.candidates) == \
+            (sp.count, sp.sumlength, sp.candidates), key
+        if kw:      # (MEM counts the plan's own locates by an upper bound)
+            assert sb.searches == sp.searches, key
     # approximate matching and the reverse complement go through the bytes
     for key in sorted(H.manifest()["c1"]["runs"]):
-        if key.startswith("approx_") and not key.endswith("b"):
+        if key.startswith("approx_"):
             spec = key[len("approx_"):]
-            doedist, k, pct = spec[0] == "e", int(spec[1:].rstrip("p")), \
-                spec.endswith("p")
+            doedist, k, pct = spec[0] == "e", int(spec[1:].rstrip("pb")), \
+                1 if spec.endswith("p") else (2 if spec.endswith("b") else 0)
             got = V.findapproxcompletematches(gi, packed, doedist, k,
                                               pct).fetch()
             assert np.array_equal(H.matches_as_ref(idx, got),

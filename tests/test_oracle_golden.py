@@ -18,8 +18,9 @@ def run_oracle(case, key):
         # approx_e2, approx_h2, approx_e2p: vmatch -complete -e 2 | -h 2 |
         # -e 2p; the distance travels in the querystart field
         spec = key[len("approx_"):]
-        m = H.oracle_approx(idx, q, spec[0] == "e", int(spec[1:].rstrip("p")),
-                            percent=spec.endswith("p"))
+        m = H.oracle_approx(idx, q, spec[0] == "e", int(spec[1:].rstrip("pb")),
+                            percent=1 if spec.endswith("p")
+                            else (2 if spec.endswith("b") else 0))
         return H.matches_as_ref(idx, m), None
     if key.startswith("complete"):
         try:

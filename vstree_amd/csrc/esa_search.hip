@@ -1108,8 +1108,9 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   }
   // MEM (-l L): first pass, then the plan of mem_workplan.inc -- aligned
   // stretches answered from one bit per text position, the rest searched
-  const bool memplan = !domum && deepok && queries->rows == nullptr &&
-                       searchlength <= 255 && maxoffsets > 1 &&
+  // (a packed batch has its bytes by now: MEM reads bytes)
+  const bool memplan = !domum && deepok && searchlength <= 255 &&
+                       maxoffsets > 1 &&
                        maxoffsets < 0xFFFFu && queries->nq < 0xFFFFFFFFull &&
                        (index->tune & 2u) == 0;
   if (memplan)
@@ -3082,7 +3083,8 @@ int make_subqueries(const vsa_index *index, const vsa_queries *queries,
   sub.q.maxlength = 0;
   for (uint64_t i = 0; i < n; i++)
   {
-    const uint64_t m = queries->hlength[which[i]];
+    const uint64_t m = queries->uniform ? queries->maxlength
+                                        : queries->hlength[which[i]];
     sub.q.hlength[i] = m;
     sub.q.minlength = std::min(sub.q.minlength, m);
     sub.q.maxlength = std::max(sub.q.maxlength, m);
@@ -3113,11 +3115,17 @@ int approx_batch(const vsa_index *index, const vsa_queries *queries,
                  int doedist, uint64_t distvalue, int percent,
                  vsa_result **result);
 
+// explicitk (the second pass of a "best of" job): the threshold of every read
+// instead of distvalue percent of its length; VSA_NO_THRESHOLD = the read is
+// left out
+#define VSA_NO_THRESHOLD 0xFFFFFFFFu
 int approx_mixed(const vsa_index *index, const vsa_queries *queries,
-                 int doedist, uint64_t distvalue, vsa_result **result)
+                 int doedist, uint64_t distvalue, vsa_result **result,
+                 const std::vector<uint32_t> *explicitk = nullptr)
 {
   const uint64_t nq = queries->nq;
   std::vector<uint64_t> exact, approx;
+  std::vector<uint32_t> approxk;
   uint64_t qlimit = nq, failk = 0, failm = 0;
   bool failshort = false;
 
@@ -3129,7 +3137,14 @@ int approx_mixed(const vsa_index *index, const vsa_queries *queries,
   }
   for (uint64_t q = 0; q < nq; q++)
   {
-    const uint64_t m = queries->hlength[q], k = (m * distvalue) / 100;
+    const uint64_t m = queries->uniform ? queries->maxlength
+                                        : queries->hlength[q],
+                   k = explicitk != nullptr ? (*explicitk)[q]
+                                            : (m * distvalue) / 100;
+    if (explicitk != nullptr && k == VSA_NO_THRESHOLD)
+    {
+      continue;
+    }
     if (k == 0)
     {
       if (m < index->pl)
@@ -3152,6 +3167,7 @@ int approx_mixed(const vsa_index *index, const vsa_queries *queries,
         break;
       }
       approx.push_back(q);
+      approxk.push_back((uint32_t) k);
     }
   }
   SubQueries sa, sb;
@@ -3170,7 +3186,9 @@ int approx_mixed(const vsa_index *index, const vsa_queries *queries,
     rc = make_subqueries(index, queries, approx, sb);
     if (rc == 0)
     {
+      apm_explicitk = explicitk != nullptr ? approxk.data() : nullptr;
       rc = approx_batch(index, &sb.q, doedist, distvalue, 1, &rb);
+      apm_explicitk = nullptr;
     }
   }
   if (rc != 0)
@@ -3288,6 +3306,101 @@ int approx_mixed(const vsa_index *index, const vsa_queries *queries,
 
 } // namespace
 
+// best[q - seqoffset] = the smallest distance among the matches of read q
+// (the distance of a match travels in its querystart field)
+__global__ void __launch_bounds__(VSA_BLOCK)
+k_best_distance(const vsa_match *__restrict__ matches, uint64_t n,
+                uint64_t seqoffset, uint32_t *__restrict__ best)
+{
+  const uint64_t i = vsa_bid() * VSA_BLOCK + threadIdx.x;
+  if (i < n)
+  {
+    atomicMin(best + (matches[i].queryseq - seqoffset),
+              (uint32_t) matches[i].querystart);
+  }
+}
+
+namespace
+{
+
+// vmatch -complete -e Kb | -h Kb, "best of" (Vmengine/initcompl.c:59-77): read
+// by read -- decidefcm restores the job's K in front of every read,
+// Vmengine/fcomplete.c:251-252 -- the reference looks for the smallest
+// threshold t <= m K / 100 at which the read has a match at all (a binary
+// search over existence checks, Vmengine/approxcompl.c:80-122) and then
+// reports the read's matches at threshold t; a read without a match within
+// m K / 100 reports nothing.  Here: one pass at the percent thresholds gives
+// every read's smallest distance, a second pass runs every read at exactly
+// that threshold (the regions, and with them the order of the matches, are
+// those of the threshold: Vmengine/splitesaapm.c:458-558).
+int approx_bestof(const vsa_index *index, const vsa_queries *queries,
+                  int doedist, uint64_t distvalue, vsa_result **result)
+{
+  const uint64_t nq = queries->nq;
+  vsa_result *first = nullptr;
+  *result = nullptr;
+  if (nq >= 0xFFFFFFFFull)
+  {
+    VSA_ERROR("a best-of batch of %lu reads is not covered by the GPU engine",
+              (unsigned long) nq);
+    return VSA_NOT_COVERED;
+  }
+  int rc = vsa_findapproxcompletematches(index, queries, doedist, distvalue,
+                                         1, &first);
+  if (rc != 0)
+  {
+    vsa_result_free(first);
+    return rc;
+  }
+  std::vector<uint32_t> best(nq, VSA_NO_THRESHOLD);
+  {
+    hipStream_t stream = index->stream;
+    vsa_dev_set_stream(stream);
+    DevBuf dbest;
+    if (vsa_set_device(index->device) != 0 || dbest.alloc((nq + 1) * 4))
+    {
+      vsa_result_free(first);
+      return -100;
+    }
+    auto run = [&]() -> int {
+      VSA_HIP(hipMemsetAsync(dbest.p, 0xFF, (nq + 1) * 4, stream));
+      if (first->count > 0)
+      {
+        k_best_distance<<<gridfor(first->count), VSA_BLOCK, 0, stream>>>(
+            first->matches, first->count, queries->seqoffset,
+            dbest.as<uint32_t>());
+        VSA_HIP(hipGetLastError());
+      }
+      if (nq > 0)
+      {
+        VSA_HIP(hipMemcpyAsync(best.data(), dbest.p, nq * 4,
+                               hipMemcpyDeviceToHost, stream));
+      }
+      VSA_HIP(hipStreamSynchronize(stream));
+      return 0;
+    };
+    rc = run();
+  }
+  const vsa_stats s1 = first->stats;
+  vsa_result_free(first);
+  if (rc != 0)
+  {
+    return rc;
+  }
+  // an exact match found by the first pass has distance 0 whichever way it
+  // was found (the percent threshold of a short read is 0: exact search,
+  // whose matches carry querystart 0 as well)
+  rc = approx_mixed(index, queries, doedist, distvalue, result, &best);
+  if (*result != nullptr)
+  {
+    (*result)->stats.searches += s1.searches;
+    (*result)->stats.total_device_ms += s1.total_device_ms;
+  }
+  return rc;
+}
+
+} // namespace
+
 extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
                                              const vsa_queries *queries,
                                              int doedist, uint64_t distvalue,
@@ -3314,6 +3427,17 @@ extern "C" int vsa_findapproxcompletematches(const vsa_index *index,
     {
       return -100;
     }
+  }
+  if (percent == 2)
+  {
+    if (index->numofchars != 4)
+    {
+      VSA_ERROR("approximate search on alphabets of %lu symbols is not "
+                "covered by the GPU engine",
+                (unsigned long) index->numofchars);
+      return VSA_NOT_COVERED;
+    }
+    return approx_bestof(index, queries, doedist, distvalue, result);
   }
   if (percent != 0 && index->bck != nullptr && index->numofchars == 4 &&
       (queries->minlength * distvalue) / 100 == 0 &&
