@@ -134,14 +134,24 @@ def parse():
                          "pipelines")
     # --path c on a box with one GPU: N replicas of the index on device 0
     ap.add_argument("--replicas-on-one-gpu", action="store_true")
+    # (tests only: the C path gives up after its setup, so that the fallback
+    # to the torch form can be rehearsed on a box with one GPU)
+    ap.add_argument("--test-fail-c-path", action="store_true",
+                    help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+# what the kernels of a default run are compiled from
+KERNEL_SOURCES = ("search_query.inc", "esa_device.hpp", "mum_workplan.inc",
+                  "mem_workplan.inc", "search_complete.inc",
+                  "selfmum_scan.inc", "mum_filter.inc", "esa_search.hip",
+                  "selfmum_search.hip", "search_common.hip")
 
 
 def kernel_source_hash():
     """identifies the kernel sources a PMC profile was taken with"""
     h = hashlib.sha1()
-    for f in ("search_query.inc", "esa_device.hpp", "mum_workplan.inc",
-              "esa_search.hip"):
+    for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "vstree_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -193,6 +203,43 @@ def family(name, mode, ms, nbytes, note, traffic_key=None, **more):
         d["traffic_source"] = _TRAFFIC.get("source")
     d.update(more)
     return d
+
+
+def counted_search_bytes(a, V, H, index, queries, host, small, m, L, w):
+    """algorithmic bytes per search, counted on exactly the searches the
+    dominant kernel runs: the plans of the first queries as the engine made
+    them (one more call with VSA_DEBUG_PLANFILE, outside the timed region),
+    every planned (query, offset) searched by the instrumented restatement.
+    -> (bytes per search, searches counted) or (None, None)"""
+    pf = os.path.join(a.workdir, "vsa_plans_%d.bin" % os.getpid())
+    os.environ["VSA_DEBUG_PLANFILE"] = pf
+    try:
+        V.findquerymatches(index, queries, L, mum=True).close()
+    finally:
+        del os.environ["VSA_DEBUG_PLANFILE"]
+    if not os.path.exists(pf):
+        return None, None
+    pl = np.fromfile(pf, dtype=np.uint32).reshape(-1, 5)[:small.nq]
+    os.unlink(pf)
+    qi, offs = [], []
+    for k in range(1, 5):
+        first, ln = pl[:, k] & 0xFFFF, pl[:, k] >> 16
+        ln = np.where(pl[:, 0] != 0, ln, 0)
+        rep = np.repeat(np.arange(len(pl)), ln)
+        within = np.arange(ln.sum()) - np.repeat(np.cumsum(ln) - ln, ln)
+        qi.append(rep)
+        offs.append(first[rep] + within)
+    qi, offs = np.concatenate(qi), np.concatenate(offs)
+    if not len(qi):
+        return None, None
+    lens = (m - offs).astype(np.uint64)
+    starts = (qi * m + offs).astype(np.uint64)
+    sufq = H.Queries(small.symbols, starts, lens)
+    cb, _ = count_bytes(H, lambda: H.oracle_complete(host, sufq), len(qi), w,
+                        int(lens.sum()))
+    # (count_bytes charges every search its whole suffix as "query symbols"; a
+    # search reads the ones it compares, which `charcomp` holds already)
+    return cb - float(lens.sum()) / len(qi), int(len(qi))
 
 
 def write_fasta(path, header, symbols, width=1 << 20):
@@ -364,13 +411,14 @@ def reference_baseline(a, V, H, genome, qsym, m, L, ncores):
         shutil.rmtree(wd, ignore_errors=True)
 
 
-def launch_ranks(a, jsonfd):
+def launch_ranks(a, jsonfd, have=None, more_args=(), more_keys=None):
     """`python bench.py --gpus N` without a launcher around it: start N ranks
     through torch.distributed.run (what the driver's own command line does),
     relay rank 0's JSON line.  device_count() does not initialise the GPU."""
     import socket
-    import torch
-    have = torch.cuda.device_count()
+    if have is None:
+        import torch
+        have = torch.cuda.device_count()
     if not a.rehearse_on_one_gpu and have < a.gpus:
         log("bench.py: --gpus %d, but this node shows %d GPU(s)"
             % (a.gpus, have))
@@ -383,8 +431,15 @@ def launch_ranks(a, jsonfd):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+           "--master-port", str(port), os.path.abspath(__file__)] + \
+        sys.argv[1:] + list(more_args)
+    # (started from inside a rank of another launcher -- the fallback of the C
+    # path --: nothing of that launcher's environment reaches the new ranks)
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith(("TORCHELASTIC_", "PET_", "ROLE_", "MASTER_"))
+                   or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK",
+                            "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE"))}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
     line = None
     for l in p.stdout.decode().splitlines():
@@ -399,6 +454,9 @@ def launch_ranks(a, jsonfd):
         log("bench.py: asked for %d GPUs, the ranks report %r"
             % (a.gpus, d.get("n_gpus")))
         sys.exit(3)
+    if more_keys:
+        d.update(more_keys)
+        line = json.dumps(d)
     os.write(jsonfd, (line + "\n").encode())
 
 
@@ -414,18 +472,13 @@ def c_path_mode(a, jsonfd, rank, world):
     queries in host memory, matches back in host memory -- PCIe-inclusive,
     named so in the metric, never the headline).
     Under a launcher with N ranks (the driver's command line) rank 0 is that
-    one process; the other ranks hold no GPU and meet it at the barriers."""
-    dist = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    one process; the other ranks hold no GPU and leave at once (the launcher
+    waits for all of them, i.e. for rank 0)."""
     if rank != 0:
-        dist.barrier()      # setup done
-        dist.barrier()      # timed region over
-        dist.barrier()
-        dist.destroy_process_group()
+        # (no torch.distributed here, not even for a barrier: torch brings a
+        # HIP runtime of its own, and libvstree_amd_multi.so drives the GPUs
+        # through the one it links -- one runtime per process)
+        log("bench.py: rank %d of %d: the C path runs in rank 0" % (rank, world))
         return
     import vstree_amd as V
     from vstree_amd import multi as M
@@ -479,6 +532,9 @@ def c_path_mode(a, jsonfd, rank, world):
     t1 = time.time()
     multi = M.Multi.replicate(index, devices)
     t_rep = time.time() - t1
+    if a.test_fail_c_path:
+        multi.close()
+        raise RuntimeError("--test-fail-c-path")
     log("setup: index %d bp (%.1f GB in HBM, deep prefix %d) built in %.1fs, "
         "%d replica(s) in %.1fs" % (n, info.device_bytes / 1e9,
                                     info.deepprefix, t_index, N, t_rep))
@@ -531,8 +587,6 @@ def c_path_mode(a, jsonfd, rank, world):
     def sync():
         for d in sorted(set(devices)):
             V.device_synchronize(d)
-        if dist is not None:
-            dist.barrier()
 
     st = None
     for _ in range(max(a.warmup, 3) if mp is not None else a.warmup):
@@ -588,7 +642,10 @@ def c_path_mode(a, jsonfd, rank, world):
         "query_suffix_searches": int(st.searches),
         # the dominant kernel on the slowest replica (HIP events); its
         # algorithmic bytes are counted at N = 1 by the single-process line
-        "roofline": {"kernel": "k_query_search_planned<256>", "bound": "hbm",
+        "roofline": {"kernel": "k_query_search_planned<uint32_t, 256, deep, "
+                               "%s, MUM>" % ("bytes" if (a.host and a.compat) or
+                                             a.reads != "packed" else "rows"),
+                     "bound": "hbm",
                      "kernel_ms": kms, "first_pass_ms": float(np.mean(first_ms)),
                      "searches_per_launch": int(st.kernel_searches) / N,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -599,13 +656,54 @@ def c_path_mode(a, jsonfd, rank, world):
     if a.host:
         out["bytes_over_pcie_per_step"] = int(nq * N * m + 16 * nq * N +
                                               32 * int(st.count))
+    if not a.quick:
+        # the kernel's algorithmic bytes, counted like the N = 1 line does: on
+        # the searches the plans of block 0 hold (test infrastructure: the
+        # instrumented CPU restatement), x the searches of one replica
+        import helpers as H
+        w = info.device_integersize // 8
+        # (replica 0, borrowed: the set owns it)
+        index = V.Index(C.c_void_p(M.lib.vsa_multi_index(multi._h, 0)))
+        t = index.download()
+        host = H.Index(n, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
+                       t["llv"], t["bck"], t["bwt"], None)
+        ns = min(nq, 20000)
+        rows = t["tis"][pos[:ns, None].astype(np.int64) +
+                        np.arange(m)[None, :]].astype(np.uint8)
+        hit = np.flatnonzero(sub[:ns] != V.NO_SUBST)
+        rows[hit, sub[hit]] = (rows[hit, sub[hit]] + step[hit]) & 3
+        small = H.Queries.uniform(np.ascontiguousarray(rows).ravel(), m)
+        block0 = V.Queries.from_host_packed(small.symbols, m, devices[0]) \
+            if a.reads == "packed" else V.Queries.from_host(
+                small.symbols, small.start, small.length, devices[0])
+        per, items = counted_search_bytes(a, V, H, index, block0, host, small,
+                                          m, L, w)
+        block0.close()
+        index._h = None
+        del t, host
+        if per is not None:
+            rf = out["roofline"]
+            nbytes = per * rf["searches_per_launch"]
+            rf.update({
+                "algorithmic_bytes_per_launch": nbytes,
+                "bytes_per_search": per, "searches_counted": items,
+                "bytes_are": "counted",
+                "achieved": nbytes / (kms * 1e-3) / 1e9,
+                "frac": nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "slowest replica per step (HIP events); algorithmic "
+                        "bytes = SURVEY 8d formula counted by the "
+                        "instrumented CPU restatement on the searches the "
+                        "plans of the first %d reads hold, x the searches of "
+                        "one replica" % small.nq})
+            tj = pmc_traffic(n, nq)
+            if tj.get("hbm_bytes_per_launch"):
+                rf["traffic"] = tj["hbm_bytes_per_launch"]
+                rf["traffic_source"] = "%s (the same kernel at N = 1)" % \
+                    tj.get("source")
     if mp is not None:
         mp.close()
     multi.close()
     os.write(jsonfd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def physical_cores():
@@ -645,6 +743,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    path_by_default = a.path is None
     if a.path is None:
         # N > 1: the C path (north_star: host code in C, RCCL for the count
         # reduction); the rehearsal switches belong to the torch form
@@ -666,7 +765,32 @@ def main():
         sys.exit(2)
     dev = 0 if a.rehearse_on_one_gpu else local_rank
     if a.path == "c":
-        return c_path_mode(a, jsonfd, rank, world)
+        try:
+            return c_path_mode(a, jsonfd, rank, world)
+        except Exception as e:
+            # No node with more than one GPU has run the C path yet.  Where it
+            # was chosen by default and fails, the job is not lost: rank 0
+            # starts the other N > 1 form (one process per GPU over
+            # torch.distributed / RCCL) and says so in the line.
+            if not path_by_default or rank != 0:
+                raise
+            import gc
+            import traceback
+            why = "%s: %s" % (type(e).__name__, e)
+            log("bench.py: the C path failed (%s); falling back to --path "
+                "torch\n%s" % (why, traceback.format_exc()))
+            e = None
+            gc.collect()
+            import vstree_amd as V
+            have = V.device_count()
+            for d in range(have):
+                V.lib.vsa_device_trim(d)
+            more = ["--path", "torch"]
+            if a.replicas_on_one_gpu:     # (the rehearsal of this very step)
+                more.append("--rehearse-on-one-gpu")
+                a.rehearse_on_one_gpu = True
+            return launch_ranks(a, jsonfd, have=have, more_args=more,
+                                more_keys={"c_path_failed": why})
 
     torch = dist = S = None
     distributed = world > 1 or a.force_distributed
@@ -949,36 +1073,8 @@ def main():
         # planned (query, offset) searched by the instrumented restatement
         counted_per_search = counted_items = None
         if not distributed:
-            pf = os.path.join(a.workdir, "vsa_plans_%d.bin" % os.getpid())
-            os.environ["VSA_DEBUG_PLANFILE"] = pf
-            try:
-                V.findquerymatches(index, queries, L, mum=True).close()
-            finally:
-                del os.environ["VSA_DEBUG_PLANFILE"]
-            if os.path.exists(pf):
-                pl = np.fromfile(pf, np.uint32).reshape(-1, 5)[:small.nq]
-                os.unlink(pf)
-                qi, offs = [], []
-                for k in range(1, 5):
-                    first, ln = pl[:, k] & 0xFFFF, pl[:, k] >> 16
-                    ln = np.where(pl[:, 0] != 0, ln, 0)
-                    rep = np.repeat(np.arange(len(pl)), ln)
-                    within = np.arange(ln.sum()) - np.repeat(
-                        np.cumsum(ln) - ln, ln)
-                    qi.append(rep)
-                    offs.append(first[rep] + within)
-                qi, offs = np.concatenate(qi), np.concatenate(offs)
-                if len(qi):
-                    lens = (m - offs).astype(np.uint64)
-                    starts = (qi * m + offs).astype(np.uint64)
-                    sufq = H.Queries(small.symbols, starts, lens)
-                    cb, _ = count_bytes(H, lambda: H.oracle_complete(host, sufq),
-                                        len(qi), w, int(lens.sum()))
-                    # (count_bytes charges every search its whole suffix as
-                    # "query symbols"; a search reads the ones it compares,
-                    # which `charcomp` holds already)
-                    counted_per_search = cb - float(lens.sum()) / len(qi)
-                    counted_items = int(len(qi))
+            counted_per_search, counted_items = counted_search_bytes(
+                a, V, H, index, queries, host, small, m, L, w)
         # SURVEY 8d / BASELINE.md: bytes of the reference's per-suffix
         # algorithm (one bucket lookup + binary search for EVERY query
         # suffix) x queries per launch
@@ -1009,7 +1105,8 @@ def main():
         traffic, traffic_source = (tj.get("hbm_bytes_per_launch"),
                                    tj.get("source"))
         out["roofline"] = {
-            "kernel": "k_query_search_planned<256>",
+            "kernel": "k_query_search_planned<uint32_t, 256, deep, %s, MUM>"
+                      % ("rows" if a.reads == "packed" else "bytes"),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
@@ -1032,23 +1129,30 @@ def main():
                     "the kernel's searches (%.1f%% of the %d per query: the "
                     "first pass and the work plan prove the others "
                     "unnecessary; all of them: %.1f kB per query); the path "
-                    "is random 16-byte slots, one 64-byte sector each"
+                    "is random 16-byte slots, one 128-byte line of HBM each "
+                    "(traffic = 2 x FETCH_SIZE + WRITE_SIZE)"
                     % (100.0 * main_searches / world / full_searches,
                        m - L + 1, bytes_per_query / 1e3)}
         if random_gs:
-            sect = (traffic / 64.0) if traffic else None
-            out["roofline"]["random_sector_ceiling"] = {
-                "measured_G_sectors_per_s": random_gs,
-                "GBs_of_64B_sectors": random_gs * 64,
-                "frac_of_hbm_peak": random_gs * 64 / HBM_PEAK_GBS,
-                "kernel_G_sectors_per_s":
-                    sect / (kms * 1e-3) / 1e9 if sect else None,
+            # round 4: what HBM charges a random read is the aligned 128-byte
+            # line (profiles/r04/README.md), so the rate below is a rate of
+            # LINES and x 128 B the streaming rate of the device -- rounds 1-3
+            # read it as 64-byte sectors (39 % of the peak)
+            lines = tj.get("read_requests_per_launch")
+            out["roofline"]["random_line_ceiling"] = {
+                "measured_G_lines_per_s": random_gs,
+                "GBs_of_128B_lines": random_gs * 128,
+                "frac_of_hbm_peak": random_gs * 128 / HBM_PEAK_GBS,
+                "kernel_G_lines_per_s":
+                    lines / (kms * 1e-3) / 1e9 if lines else None,
                 "kernel_frac_of_ceiling":
-                    sect / (kms * 1e-3) / 1e9 / random_gs if sect else None,
+                    lines / (kms * 1e-3) / 1e9 / random_gs if lines else None,
+                "useful_bytes_per_line":
+                    executed_bytes_launch / lines if lines else None,
                 "note": "random 16-byte reads of the slot table, 4 in flight "
                         "per lane, every lane its own address sequence "
-                        "(vsa_measure_table_read); the kernel's sectors = "
-                        "PMC traffic / 64"}
+                        "(vsa_measure_table_read); the kernel's lines = read "
+                        "requests of the PMC pass (FETCH_SIZE x 1024 / 64)"}
         fams = []
         if world == 1:
             # every query once, with the whole query: priced like the
@@ -1132,11 +1236,24 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
         "occ*(w + 16))" % cbytes, traffic_key="k_complete_search", queries=nq,
         matches=s.count, call_device_ms=s.total_device_ms))
     s = best(lambda: V.findquerymatches(index, queries, L), reps=2)
+    # since round 4 the MEM plan (mem_workplan.inc) leaves the search kernel
+    # the offsets it cannot answer from the repeat bits: the kernel is priced
+    # on the searches it RUNS (the per-search average over all suffixes x its
+    # work-items: modelled, like K2 before round 3), the call on all of them
+    allbytes = bytes_per_query * nq
+    ran = float(s.kernel_searches)
+    persearch = bytes_per_query / (m - L + 1)
     fams.append(family(
-        "k_query_search<uint32_t, MEM, deep, 256>", "-l %d (MEM)" % L,
-        s.search_kernel_ms, bytes_per_query * nq,
-        "all %d suffixes of every query are searched; bytes = %.0f B/query"
-        % (m - L + 1, bytes_per_query), traffic_key="k_query_search_mem",
+        "k_query_search_planned<uint32_t, 256, deep, MEM>", "-l %d (MEM)" % L,
+        s.search_kernel_ms, persearch * ran,
+        "the MEM plan leaves %d of the %d query suffixes to the search "
+        "kernel (%.1f %%); bytes = %.0f B per search (average over all "
+        "suffixes, modelled) x the searches it runs; the whole call does the "
+        "work of %.0f B/query x %d queries = %.1f GB in %.2f ms"
+        % (s.kernel_searches, (m - L + 1) * nq,
+           100.0 * ran / ((m - L + 1) * nq), persearch, bytes_per_query, nq,
+           allbytes / 1e9, s.total_device_ms),
+        traffic_key="k_query_search_mem",
         queries=nq, matches=s.count, call_device_ms=s.total_device_ms))
     # BASELINE configs[4]: -complete -e 2 on 150 bp reads
     s = best(lambda: V.findapproxcompletematches(index, q150, True, 2), reps=3)
@@ -1291,7 +1408,7 @@ def selfmum_family(a, V, n, L, dev):
     s = min(got[1:], key=lambda x: x.search_kernel_ms)
     idx.close()
     return family(
-        "k_selfmum_peaks<4, nontemporal>",
+        "k_selfmum_peaks<nontemporal, uint32_t>",
         "-mum -l %d on an index that holds its queries (the suftab scan, "
         "fmumself.c)" % L, s.search_kernel_ms, 2.0 * (len(tis) + 1),
         "streams lcptab and bwttab once: 2(n+1) bytes; the whole call "
@@ -1426,7 +1543,7 @@ def selfmum_mode(a, V, S, torch, dist, rank, world, dev, jsonfd):
                                    % (len(tis), L, world),
                        "index_build_s": round(t_index, 2)},
             "matches": totals[0],
-            "roofline": family("k_selfmum_peaks<4, nontemporal>",
+            "roofline": family("k_selfmum_peaks<nontemporal, uint32_t>",
                                "rank 0's range", ms, nbytes,
                                "lcptab + bwttab of the range, once")}
         sys.stdout.flush()

@@ -502,6 +502,8 @@ int vsa_findtandems(const vsa_index *index, uint64_t searchlength,
   database and the query part of one index.  Reported like the reference's
   Outputfunction(outinfo, len, start1, start2): length, dbstart = start1,
   queryseq = start2 (absolute), querystart = 0; suffix array order.
+  VSA_NOT_COVERED for alphabets of more than 128 symbols (mkvtree -smap with
+  such a map: the reference's engine keeps those).
 */
 int vsa_findmaximaluniquematches(const vsa_index *index,
                                  uint64_t searchlength, vsa_result **result);
@@ -686,6 +688,10 @@ int vsa_device_synchronize(int device);
 /* temporaries and freed result lists are recycled inside the library; this
    hands the cached device memory back to HIP */
 int vsa_device_trim(int device);
+/* what HIP reports as free / total memory of the device (the library's own
+   cache of freed blocks counts as used until vsa_device_trim): how much room
+   an index has, and what a failed job must leave unchanged */
+int vsa_device_meminfo(int device, uint64_t *freebytes, uint64_t *totalbytes);
 /* measured device-to-device streaming read rate in GB/s (roofline
    denominator cross-check in bench.py) */
 int vsa_measure_stream_read(uint64_t bytes, int device, double *gbps);

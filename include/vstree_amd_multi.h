@@ -35,9 +35,12 @@ extern "C" {
 
 typedef struct vsa_multi vsa_multi;
 
-/* the host tables uploaded to every device of the list, all at the same time
-   (one PCIe link per GPU); a device may be named twice (two replicas on one
-   GPU: how the tests run on a one-GPU box) */
+/* the host tables uploaded to the first device of the list, the derived
+   search tables made there, and every other replica copied from it device to
+   device (as vsa_multi_replicate does): all replicas of a set have the same
+   tables of the same depth (vsa_index_info.deepprefix), whatever memory each
+   device had free.  A device may be named twice (two replicas on one GPU: how
+   the tests run on a one-GPU box) */
 int vsa_multi_from_tables(const vsa_tables *tables, const int *devices,
                           uint32_t ndevices, vsa_multi **multi);
 

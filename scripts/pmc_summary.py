@@ -18,7 +18,7 @@ from bench import kernel_source_hash  # noqa: E402
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = re.sub(r"\(.*", "", name)
-    return name[:58]
+    return name[:80]
 
 
 def main():
@@ -56,14 +56,15 @@ def main():
                         float(r["Counter_Value"])
     step_bytes = None
     if step:
-        # FETCH_SIZE counts wide coalesced reads at half their size on gfx950
-        # (MI355X_MICROARCH.md): doubled for every kernel but the searches,
-        # whose reads are random 8/16-byte words, one 64-byte request each
-        random = ("k_mum_first", "k_mum_plan", "k_query_search",
-                  "k_complete_search", "k_mum_anchor")
+        # FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but a request is an aligned
+        # 128-byte line -- for wide coalesced streams (MI355X_MICROARCH.md) and,
+        # measured in round 4, for random 16-byte reads as well
+        # (profiles/r04/README.md, pmc_line_probe_summary.txt: two sectors of
+        # one line = ONE request, and lines arrive at the streaming rate):
+        # doubled for every kernel
         step_bytes, per_kernel = 0.0, collections.defaultdict(float)
         for (k, c), v in step.items():
-            fac = 2 if (c == "FETCH_SIZE" and not k.startswith(random)) else 1
+            fac = 2 if c == "FETCH_SIZE" else 1
             per_kernel[k] += v * fac * 1024
             step_bytes += v * fac * 1024
     counters = sorted({c for k in sums for c in sums[k]})
@@ -82,9 +83,12 @@ def main():
     if traffic:
         # the MUM search of the headline workload: the planned form since
         # round 2 (mum_workplan.inc), the work-list form before
-        dom = ([k for k in sums if k.startswith("k_query_search_planned")] or
-               [k for k in sums if k.startswith("k_query_search<unsigned int, true")] or
-               [k for k in sums if k.startswith("k_query_search")])
+        # (template arguments: index width, workgroup, deep tables, reads as
+        # 2-bit rows, MUM; the default bench searches packed reads)
+        dom = ([k for k in sums if k.startswith(
+                    "k_query_search_planned<unsigned int, 256, true, true, true")] or
+               [k for k in sums if k.startswith(
+                    "k_query_search_planned<unsigned int, 256, true, false, true")])
         if dom:
             k = dom[0]
             mean = {c: sums[k][c] / launches[k][c] for c in sums[k]}
@@ -94,29 +98,38 @@ def main():
                  "WRITE_SIZE_KiB": mean.get("WRITE_SIZE"),
                  "TCC_HIT_sum": mean.get("TCC_HIT_sum"),
                  "TCC_MISS_sum": mean.get("TCC_MISS_sum"),
+                 "read_requests_per_launch":
+                     mean.get("FETCH_SIZE", 0) * 1024 / 64.0,
                  "hbm_bytes_per_launch":
+                     (2 * mean.get("FETCH_SIZE", 0) + mean.get("WRITE_SIZE", 0))
+                     * 1024,
+                 "hbm_bytes_per_launch_at_64B_per_request":
                      (mean.get("FETCH_SIZE", 0) + mean.get("WRITE_SIZE", 0))
                      * 1024,
-                 "note": "random 8/16-byte reads: TCC_MISS_sum x 64 B = "
-                         "FETCH_SIZE x 1024 (one 64-byte request per L2 "
-                         "miss); the x2 correction of MI355X_MICROARCH.md "
-                         "for wide coalesced streams is not applied",
+                 "note": "FETCH_SIZE = read requests x 64 B; a request is an "
+                         "aligned 128-byte line, for random 16-byte reads as "
+                         "for wide streams (profiles/r04/README.md: two "
+                         "sectors of one line are ONE request; "
+                         "MI355X_MICROARCH.md prescribes the factor 2 for "
+                         "streams): hbm_bytes_per_launch = 2 x FETCH_SIZE + "
+                         "WRITE_SIZE.  Rounds 1-3 quoted the 64-byte figure "
+                         "(kept next to it)",
                  "kernel_source_sha16": kernel_source_hash(),
-                 "round": 3, "source": out}
+                 "round": 4, "source": out}
             if step_bytes:
                 j["step_hbm_bytes"] = step_bytes
                 j["step_hbm_bytes_by_kernel"] = dict(sorted(
                     per_kernel.items(), key=lambda kv: -kv[1])[:16])
-            # the other kernel families bench.py prices: (FETCH_SIZE +
-            # WRITE_SIZE) KiB per launch.  Streaming kernels read in wide
-            # coalesced requests, which FETCH_SIZE counts at half their size on
-            # gfx950 (MI355X_MICROARCH.md, HBM counters): doubled for them.
+            # the other kernel families bench.py prices: (2 x FETCH_SIZE +
+            # WRITE_SIZE) KiB per launch (see the note above)
             fams = {}
             for key, pattern, factor in (
-                    ("k_mum_first", "k_mum_first<unsigned int, true", 1),
-                    ("k_complete_search", "k_complete_search<unsigned int, true, true", 1),
-                    ("k_query_search_mem", "k_query_search<unsigned int, false, true", 1),
-                    ("k_apm_banded", "k_apm_banded", 1),
+                    ("k_mum_first", "k_mum_first<unsigned int, true", 2),
+                    ("k_mum_plan", "k_mum_plan<unsigned int, true", 2),
+                    ("k_complete_search", "k_complete_search<unsigned int, true, true", 2),
+                    ("k_query_search_mem", "k_query_search_planned<unsigned int, 256, true, false, false", 2),
+                    ("k_mem_plan", "k_mem_plan", 2),
+                    ("k_apm_banded", "k_apm_banded", 2),
                     ("k_selfmum_peaks", "k_selfmum_peaks", 2)):
                 for k2 in sums:
                     if k2.startswith(pattern) and "FETCH_SIZE" in sums[k2]:

@@ -53,6 +53,37 @@ def test_multi_gpu_library_exports_its_header(V):
     assert "libvstree_amd.so" in need and "librccl" in need
 
 
+def test_which_hip_runtime_the_mirror_binds_to_can_be_said_explicitly():
+    """VSTREE_AMD_RUNTIME=own|host|auto (vstree_amd/__init__.py): the explicit
+    values do not depend on the order of imports and fail where they cannot
+    hold; the multi-GPU mirror refuses the library variant it was not linked
+    with"""
+    import sys
+
+    def run(value, code):
+        c = subprocess.run([sys.executable, "-c", code],
+                           env=dict(os.environ, VSTREE_AMD_RUNTIME=value),
+                           cwd=H.ROOT, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+        return c.returncode, c.stdout.decode(), c.stderr.decode()
+
+    show = "import vstree_amd as V; print(V.LIBPATH)"
+    rc, out, err = run("own", show)
+    assert rc == 0 and out.strip().endswith("libvstree_amd.so")
+    rc, out, err = run("host", show)
+    assert rc != 0 and "no HIP runtime is mapped" in err
+    rc, out, err = run("bogus", show)
+    assert rc != 0 and "expected own, host or auto" in err
+    # torch first: auto and host take the variant without a runtime of its
+    # own, own refuses, and so does the multi-GPU mirror
+    rc, out, err = run("auto", "import torch; " + show)
+    assert rc == 0 and out.strip().endswith("libvstree_amd_nort.so"), err
+    rc, out, err = run("own", "import torch; " + show)
+    assert rc != 0 and "two HIP runtimes" in err
+    rc, out, err = run("auto", "import torch; import vstree_amd.multi")
+    assert rc != 0 and "without torch" in err
+
+
 def test_synthetic_generator_matches_recorded_md5(V):
     m = H.manifest()["c1"]
     g, q, n, nq, mm = H.synth_c1()

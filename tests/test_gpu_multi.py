@@ -86,6 +86,55 @@ def test_replicas_answer_approximate_matching(V, MG, world):
     m.close()
 
 
+def test_a_declined_job_gives_its_memory_back_and_replicas_are_alike(V, MG):
+    """ a job the engine declines (VSA_NOT_COVERED: reads beyond 512
+    symbols in approximate matching) and a job the reference ends with an
+    error leave the devices as they found them -- no buffer of an exchange
+    that never ran stays behind; and the replicas of a set made from host
+    tables are copies of ONE upload: the same derived tables of the same depth
+    whatever memory the device had free when each of them arrived"""
+    idx, q, m = tables(MG, "c5", [0, 0, 0])
+    depths = set()
+    for r in range(3):
+        h = V.Index(H.C.c_void_p(MG.lib.vsa_multi_index(m._h, r)))
+        info = h.info()
+        h._h = None                       # borrowed: the set owns it
+        depths.add((info.deepprefix, info.device_bytes))
+    assert len(depths) == 1
+    # warm every path once, then compare free memory around failing jobs
+    rng = np.random.default_rng(5)
+    longreads = H.Queries.uniform(rng.integers(0, 4, 6 * 600).astype(np.uint8),
+                                  600)
+    short = H.fasta_queries(H.os.path.join(H.GOLDEN, "short.fna"))
+    mixed = H.Queries.from_list([q.symbols[:150], q.symbols[400:550],
+                                 q.symbols[200:203], q.symbols[600:750]])
+
+    def failing_jobs():
+        got, st, rc, msg = m.findapproxcompletematches(
+            longreads.symbols, longreads.start, longreads.length, True, 2)
+        assert rc == V.NOT_COVERED, (rc, msg)
+        assert len(got) == 0
+        got, st, rc, msg = m.findapproxcompletematches(
+            mixed.symbols, mixed.start, mixed.length, True, 3)
+        assert rc != 0 and "not allowed" in msg
+        got, st, rc, msg = m.findmatches(MG.MUM, short.symbols, short.start,
+                                         short.length, 3)
+        assert rc < 0 and "must be >=" in msg
+
+    failing_jobs()
+    before = V.device_meminfo(0)[0]
+    for _ in range(3):
+        failing_jobs()
+    after = V.device_meminfo(0)[0]
+    assert after >= before - (1 << 20), (before, after)
+    # and the set still answers
+    got, st, rc, msg = m.findapproxcompletematches(
+        q.symbols, q.start, q.length, True, 4, 2)
+    assert rc == 0 and np.array_equal(H.matches_as_ref(idx, got),
+                                      H.expected("c5", "approx_e4b"))
+    m.close()
+
+
 def device_blocks(V, q, world):
     """the queries of a case cut into `world` contiguous blocks (the split of
     vsa_multi_findmatches), each uploaded to device 0 with its global offset"""
@@ -406,6 +455,50 @@ def test_bench_c_path_with_replicas_on_one_gpu():
         assert x["candidates"] == b["candidates"]
     for x in (a, c):
         assert x["query_suffix_searches"] == b["query_suffix_searches"]
+
+
+def test_bench_c_path_under_the_drivers_launcher():
+    """how the driver starts the scaling run: `python -m torch.distributed.run
+    --nproc-per-node N bench.py --gpus N`.  The C path runs in rank 0 (one
+    process, a host thread per GPU, no torch in it: one HIP runtime per
+    process), the other ranks leave; ONE line for N GPUs comes out.  And where
+    the C path fails the job is not lost: rank 0 starts the other N > 1 form
+    and the line says so (rehearsed here with two replicas / two gloo ranks on
+    the one GPU)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    bench = H.os.path.join(H.ROOT, "bench.py")
+    common = ["--gpus", "2", "--replicas-on-one-gpu", "--genome", "3e7",
+              "--queries", "150000", "--steps", "2", "--warmup", "1",
+              "--quick", "--cpu-sample", "0"]
+
+    def launch(*more):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        c = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+             "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(port), bench] + common + list(more),
+            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert c.returncode == 0, c.stderr.decode()[-3000:]
+        lines = [l for l in c.stdout.decode().splitlines()
+                 if l.startswith("{")]
+        assert len(lines) == 1, c.stdout.decode()[-2000:]
+        return json.loads(lines[0]), c.stderr.decode()
+
+    a, err = launch()
+    assert a["n_gpus"] == 2 and a["launcher_ranks"] == 2
+    assert "resident in HBM" in a["config"]["path"]
+    assert "c_path_failed" not in a
+    assert "rank 1 of 2: the C path runs in rank 0" in err
+    b, err = launch("--test-fail-c-path")
+    assert b["n_gpus"] == 2 and b["ranks"] == 2
+    assert b["c_path_failed"] == "RuntimeError: --test-fail-c-path"
+    assert b["matches"] == a["matches"] > 250000
+    assert b["candidates"] == a["candidates"]
 
 
 def test_queries_in_any_order_and_outside_the_buffer(V, MG):

@@ -215,6 +215,34 @@ def test_index_open_reads_mkvtree_files(V, tmp_path):
     assert np.array_equal(got, H.expected("grumbach_all", "selfmum14"))
 
 
+def test_self_index_scan_declines_alphabets_beyond_128_symbols(V):
+    """ the streaming pass reads "special symbol" off bit 7 of the
+    bwt byte, which holds for symbol codes below 128 only: an index over a
+    larger alphabet (mkvtree -smap) is declined, one over 128 symbols is
+    searched and equals the oracle"""
+    rng = np.random.default_rng(128)
+    for numofchars, ok in ((128, True), (129, False), (200, False)):
+        db = rng.integers(0, numofchars, 3000).astype(np.uint8)
+        qy = db[500:2500].copy()
+        qy[rng.random(len(qy)) < 0.02] = numofchars - 1
+        tis = np.concatenate([db, [H.SEPARATOR], qy]).astype(np.uint8)
+        idx = H.oracle_build_index(tis, numofchars, prefixlength=1)
+        idx.querysepposition, idx.hasqueries = len(db), True
+        gi = V.Index.from_tables(idx.n, idx.prefixlength, numofchars, idx.tis,
+                                 idx.suf, idx.lcp, idx.llv, idx.bck, idx.bwt,
+                                 len(db), True)
+        if ok:
+            got = V.findmaximaluniquematches(gi, 8).fetch()
+            assert len(got) > 10
+            assert np.array_equal(got, H.oracle_selfmum(idx, 8))
+        else:
+            with pytest.raises(V.VsaError) as e:
+                V.findmaximaluniquematches(gi, 8)
+            assert e.value.code == V.NOT_COVERED
+            assert "not covered" in e.value.message
+        gi.close()
+
+
 def test_self_index_scan_by_ranges(V):
     """vsa_findmaximaluniquematches_range (third row): any tiling
     of the reference's loop i = 2 .. n-1 (fmumself.c:33) into ranges gives,
@@ -1043,24 +1071,14 @@ def test_inconsistent_tables_are_refused_on_upload(V):
         assert e.value.code == -2 and what in e.value.message, kw
 
 
-@pytest.mark.parametrize("name,value", [("VSA_TANDEM_ISA", "1")])
-def test_round2_experiment_switches_give_the_same_lists(V, name, value,
-                                                        monkeypatch):
-    """the tandem kernel on the inverse suffix array (selfmatch_search.inc):
-    a measured alternative that stays in the library"""
-    monkeypatch.setenv(name, value)
-    if name == "VSA_TANDEM_ISA":
-        for case, key in (("at1mb", "tandem40"), ("at1mb", "tandem5"),
-                          ("grumbach", "tandem3"), ("largepat", "tandem8")):
-            idx, _ = H.load_case(case)
-            got = H.repeats_as_ref(idx, V.findtandems(
-                gpu_index(V, case), int(key[len("tandem"):])).fetch())
-            assert np.array_equal(got, H.expected(case, key)), (case, key)
-        return
-    idx, q = H.load_case("c1")
-    gi, gq = gpu_index(V, "c1"), gpu_queries(V, q)
-    for key, kw in (("mum20", dict(mum=True)),
-                    ("mumcand20", dict(mum=True, cand=True))):
-        got = H.matches_as_ref(idx, V.findquerymatches(gi, gq, 20,
-                                                       **kw).fetch())
-        assert np.array_equal(got, H.expected("c1", key)), (name, key)
+def test_tandem_kernel_on_the_inverse_suffix_array(V, monkeypatch):
+    """VSA_TANDEM_ISA=1 (selfmatch_search.inc): window comparisons by two
+    loads of the inverse suffix array instead of the text -- an option for
+    callers that ask repeatedly; the lists must not change"""
+    monkeypatch.setenv("VSA_TANDEM_ISA", "1")
+    for case, key in (("at1mb", "tandem40"), ("at1mb", "tandem5"),
+                      ("grumbach", "tandem3"), ("largepat", "tandem8")):
+        idx, _ = H.load_case(case)
+        got = H.repeats_as_ref(idx, V.findtandems(
+            gpu_index(V, case), int(key[len("tandem"):])).fetch())
+        assert np.array_equal(got, H.expected(case, key)), (case, key)

@@ -31,6 +31,8 @@ def _loaded_hip_runtime():
         pass
     return None
 
+OWN_HIP_RUNTIME = "/opt/rocm/lib/libamdhip64.so"
+
 SEPARATOR = 255
 WILDCARD = 254
 NO_SUBST = 0xFFFFFFFF
@@ -106,10 +108,28 @@ def _load():
             "%s is missing: build it with `make -C vstree_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback"
             % LIBPATH)
+    # One HIP runtime per process.  VSTREE_AMD_RUNTIME says which:
+    #   own   libvstree_amd.so, which links /opt/rocm/lib/libamdhip64.so
+    #   host  libvstree_amd_nort.so: the same objects, bound to the runtime the
+    #         process has mapped already (a PyTorch wheel's, under torch/lib)
+    #   auto  (default) host if a runtime is mapped at import time, own if not
+    # -- the explicit values are for callers that do not want the outcome to
+    # depend on the order of their imports: each fails where it cannot hold.
+    choice = os.environ.get("VSTREE_AMD_RUNTIME", "auto")
+    if choice not in ("auto", "own", "host"):
+        raise ImportError("VSTREE_AMD_RUNTIME=%r: expected own, host or auto"
+                          % choice)
     hip = _loaded_hip_runtime()
-    if hip is not None and os.path.exists(LIBPATH_NORT):
-        # one HIP runtime per process: bind to the one that is already here
-        # (import torch BEFORE vstree_amd when both are used)
+    if choice == "host" and hip is None:
+        raise ImportError("VSTREE_AMD_RUNTIME=host, but no HIP runtime is "
+                          "mapped in this process yet (import torch first)")
+    if choice == "own" and hip is not None and \
+            os.path.realpath(hip) != os.path.realpath(OWN_HIP_RUNTIME):
+        raise ImportError("VSTREE_AMD_RUNTIME=own, but this process has "
+                          "mapped %s: two HIP runtimes do not share a device"
+                          % hip)
+    if choice == "host" or (choice == "auto" and hip is not None and
+                            os.path.exists(LIBPATH_NORT)):
         C.CDLL(hip, mode=C.RTLD_GLOBAL)
         LIBPATH = LIBPATH_NORT
     lib = C.CDLL(LIBPATH)
@@ -209,6 +229,7 @@ def _load():
         "vsa_device_count": (I, []),
         "vsa_device_synchronize": (I, [I]),
         "vsa_device_trim": (I, [I]),
+        "vsa_device_meminfo": (I, [I, C.POINTER(U64), C.POINTER(U64)]),
         "vsa_measure_stream_read": (I, [U64, I, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -890,6 +911,15 @@ def device_download(array, dptr, device=0):
     """device memory -> a contiguous numpy array (its size decides)"""
     assert array.flags["C_CONTIGUOUS"]
     _check(lib.vsa_device_download(_ptr(array), dptr, array.nbytes, device))
+
+
+def device_meminfo(device=0, trim=True):
+    """(free, total) bytes of the device, the library's cache handed back"""
+    if trim:
+        _check(lib.vsa_device_trim(device))
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _check(lib.vsa_device_meminfo(device, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def device_free(p, device=0):

@@ -257,3 +257,23 @@ extern "C" int vsa_device_trim(int device)
   vsa_dev_trim();
   return 0;
 }
+
+extern "C" int vsa_device_meminfo(int device, uint64_t *freebytes,
+                                  uint64_t *totalbytes)
+{
+  size_t f = 0, t = 0;
+  if (vsa_set_device(device) != 0)
+  {
+    return -100;
+  }
+  VSA_HIP(hipMemGetInfo(&f, &t));
+  if (freebytes != nullptr)
+  {
+    *freebytes = f;
+  }
+  if (totalbytes != nullptr)
+  {
+    *totalbytes = t;
+  }
+  return 0;
+}

@@ -1465,3 +1465,18 @@ vsa_wave_reserve01(unsigned long long *cursor, bool one)
   base = vsa_shfl64(base, 0);
   return base + before;
 }
+
+// inclusive prefix sum over the 64 lanes in vector operations only: shifts
+// inside the rows of 16 lanes, then the last lane of a row broadcast to the
+// rows behind it (lanes without a source add 0: bound_ctrl / the old value)
+__device__ __forceinline__ uint32_t vsa_wave_inclusive_sum(uint32_t v)
+{
+  int x = (int) v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31
+  return (uint32_t) x;
+}

@@ -561,31 +561,23 @@ extern "C" int vsa_multi_from_tables(const vsa_tables *tables,
     return -1;
   }
   *multi = nullptr;
-  vsa_multi *m = new vsa_multi;
-  m->dev.assign(devices, devices + ndevices);
-  m->ix.assign(ndevices, nullptr);
-  std::vector<int> rcs(ndevices, 0);
-  std::vector<std::string> msgs(ndevices);
-  onallreplicas(ndevices, [&](uint32_t r) {
-    rcs[r] = vsa_index_from_tables(tables, m->dev[r], &m->ix[r]);
-    if (rcs[r] != 0)
-    {
-      msgs[r] = vsa_messagespace();
-    }
-  });
-  for (uint32_t r = 0; r < ndevices; r++)
+  // The tables go to the first device once; the other replicas are copies of
+  // it, device to device (vsa_multi_replicate).  An upload per device would
+  // let every device choose the depth of its derived tables from the memory
+  // it happens to have free (index_derive.hip): replicas of one set must not
+  // differ in the kernels they run.
+  vsa_index *first = nullptr;
+  int rc = vsa_index_from_tables(tables, devices[0], &first);
+  if (rc != 0)
   {
-    if (rcs[r] != 0)
-    {
-      seterror(msgs[r]);
-      const int rc = rcs[r];
-      vsa_multi_close(m);
-      return rc;
-    }
+    return rc; // (the message is in this thread's buffer already)
   }
-  commission(m);
-  *multi = m;
-  return 0;
+  rc = vsa_multi_replicate(first, devices, ndevices, multi);
+  if (rc != 0)
+  {
+    vsa_index_close(first);
+  }
+  return rc;
 }
 
 extern "C" int vsa_multi_replicate(vsa_index *first, const int *devices,

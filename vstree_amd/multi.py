@@ -48,7 +48,17 @@ def _load():
     if not os.path.exists(LIBPATH):
         raise ImportError("%s is missing: make -C vstree_amd/csrc" % LIBPATH)
     # libvstree_amd.so is mapped already (import vstree_amd): the multi
-    # library binds to that copy
+    # library binds to that copy -- which has to be the one it was linked
+    # with.  In a process that carries another HIP runtime (torch) the mirror
+    # has loaded libvstree_amd_nort.so, and this library would bring
+    # libvstree_amd.so and a second runtime in beside it.
+    if V.LIBPATH != os.path.join(os.path.dirname(LIBPATH),
+                                 "libvstree_amd.so"):
+        raise ImportError(
+            "vstree_amd.multi drives the GPUs through the HIP runtime "
+            "libvstree_amd.so links; this process has mapped another one (%s "
+            "is loaded): use it from a process without torch "
+            "(VSTREE_AMD_RUNTIME=own makes that explicit)" % V.LIBPATH)
     lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -18,6 +18,12 @@ import numpy as np
 MATCH_WORDS = 4   # vsa_match = 4 x uint64
 
 
+def is_rccl(dist):
+    """the process group runs on RCCL (torch names it "nccl"; a group made
+    with a device map reports e.g. "cpu:gloo,cuda:nccl")"""
+    return "nccl" in str(dist.get_backend())
+
+
 def shard_range(total, rank, world):
     """contiguous block of rank: (first, count); blocks differ by at most 1"""
     base, extra = divmod(int(total), int(world))
@@ -84,7 +90,7 @@ def _exchange_rows(dist, torch, rows, dest, device):
     rows = rows[order].contiguous()
     send = torch.bincount(dest, minlength=world).to(torch.int64)
     recv = torch.zeros_like(send)
-    if dist.get_backend() == "nccl":   # (decided alike on every rank)
+    if is_rccl(dist):   # (decided alike on every rank)
         dist.all_to_all_single(recv, send)
         out = torch.empty((int(recv.sum().item()), MATCH_WORDS),
                           dtype=torch.int64, device=device)
@@ -163,9 +169,18 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     # decided the same way on every rank before anything is sent (a fallback
     # inside `except` would let ranks that fail for another reason issue a
     # different collective than the others)
-    rccl = dist.get_backend() == "nccl"
+    rccl = is_rccl(dist)
     if meta_on_device and not rccl:
         raise ValueError("meta_on_device needs the RCCL backend")
+    if meta_on_device and \
+            torch.cuda.current_stream() != torch.cuda.default_stream():
+        # vsa_result_partition_device / vsa_findmumcandidates_grouped queue
+        # their last kernels on the legacy default stream and do not wait
+        # (include/vstree_amd.h): the collectives below are ordered behind
+        # them only if they are issued on that stream too
+        raise RuntimeError("meta_on_device: the split sizes are written on "
+                           "the default stream; call this outside "
+                           "torch.cuda.stream(...) contexts")
     if rccl and (_STAGED or meta_on_device):
         # one tensor in, one out, through page-locked staging buffers kept
         # from batch to batch: no allocation, no pageable copy
