@@ -1291,8 +1291,10 @@ def end_to_end(V, index, dg, n, nq, m, L, dev):
     downloaded).  The page-locked rows are filled before the clock starts (a
     slot keeps its reads between jobs): what is timed is host memory -> host
     memory, not the production of the reads; the packer's own rate (one host
-    thread) is reported next to it.  `bytes`: the same two jobs with the reads
-    as bytes (the form of round 3), for comparison."""
+    thread, and the threads of this GPU's share of the box) is reported next
+    to it, and `mumcand_incl_packing` runs the steady state with the packing
+    of every batch inside the clock.  `bytes`: the same two jobs with the
+    reads as bytes (the form of round 3), for comparison."""
     pos, sub, step = V.synth_query_plan(n, 3 * nq, m, seed=777)
     dq = V.device_malloc(nq * m + 64, dev)
     hbuf = np.empty(nq * m, np.uint8)
@@ -1307,8 +1309,13 @@ def end_to_end(V, index, dg, n, nq, m, L, dev):
         return hbuf
 
     packrate = [0.0]
+    packthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+    hbatches = []     # (filled by the first job: the three batches as bytes)
 
-    def job(p, batches, refill):
+    def job(p, batches, refill, packthreads_=0):
+        """refill: the slots get their reads (untimed callers); packthreads_
+        > 0: every batch is packed from its bytes into the slot INSIDE this
+        call, on that many host threads (the slots' rows do not count as given)"""
         sub_, got, total = 0, 0, 0
         while got < batches:
             slot = None
@@ -1318,14 +1325,20 @@ def end_to_end(V, index, dg, n, nq, m, L, dev):
                 if p.packed:
                     rows, special = slot
                     key = rows.ctypes.data
-                    if refill:
+                    if refill or packthreads_:
                         ns = C.c_uint64(0)
-                        src = reads(sub_ % 3)
+                        if len(hbatches) < 3:
+                            hbatches.append(reads(len(hbatches)).copy())
+                        src = hbatches[sub_ % 3]
                         t0 = time.perf_counter()
-                        V._check(V.lib.vsa_pack_reads(
+                        V._check(V.lib.vsa_pack_reads_mt(
                             src.ctypes.data, nq, m, m, rows.ctypes.data,
-                            special.ctypes.data, p.maxspecial, C.byref(ns)))
-                        packrate[0] = nq / (time.perf_counter() - t0)
+                            special.ctypes.data, p.maxspecial, C.byref(ns),
+                            max(packthreads_, 1)))
+                        if not packthreads_:
+                            packrate[0] = max(
+                                packrate[0],
+                                nq / (time.perf_counter() - t0))
                         job.ns[key] = int(ns.value)
                     V._check(V.lib.vsa_pipeline_submit_packed(
                         p._h, nq, job.ns[key]))
@@ -1366,6 +1379,23 @@ def end_to_end(V, index, dg, n, nq, m, L, dev):
                     "MUM list of the whole job in host memory (%.2f GB), "
                     "global filter included"
                     % (L, human(nq), up / 1e9, nmums * 32 / 1e9)}
+        if packed:
+            # the MUM list at 16 bytes per match (vsa_pipeline_finish16): what
+            # a -mum job waits for at its end is the list on the host link
+            p = V.Pipeline(index, 3, L, m, nq, packed=True, maxspecial=1024)
+            job(p, 3, True)
+            p.finish(copy=False, compact=True)
+            t0 = time.perf_counter()
+            job(p, 3, False)
+            mums, st = p.finish(copy=False, compact=True)
+            dt = time.perf_counter() - t0
+            assert int(len(mums)) == nmums
+            p.close()
+            out["mum16"] = {
+                "end_to_end_queries_per_s": 3 * nq / dt, "queries": 3 * nq,
+                "ms": dt * 1e3, "mums": nmums,
+                "what": "as mum, the list as vsa_match16 (%.2f GB instead of "
+                        "%.2f)" % (nmums * 16 / 1e9, nmums * 32 / 1e9)}
         p = V.Pipeline(index, 2, L, m, nq, packed=packed, maxspecial=1024)
         job(p, 3, True)
         t0 = time.perf_counter()
@@ -1379,6 +1409,24 @@ def end_to_end(V, index, dg, n, nq, m, L, dev):
                     "up each), every batch's candidate list (%.2f GB) back "
                     "in host memory"
                     % (L, human(nq), up / 1e9, total / 12 * 32 / 1e9)}
+        if packed:
+            # the same steady state with the packing of every batch inside
+            # the clock: bytes in pageable host memory -> rows in the slot
+            # (vsa_pack_reads_mt) -> PCIe -> search -> list in host memory
+            p = V.Pipeline(index, 2, L, m, nq, packed=True, maxspecial=1024)
+            job(p, 3, True)
+            t0 = time.perf_counter()
+            total = job(p, 12, False, packthreads_=packthreads)
+            dt = time.perf_counter() - t0
+            p.close()
+            out["mumcand_incl_packing"] = {
+                "end_to_end_queries_per_s": 12 * nq / dt,
+                "ms_per_batch": dt / 12 * 1e3, "matches": int(total),
+                "pack_threads": packthreads,
+                "what": "as mumcand, but every batch starts as one byte per "
+                        "symbol in pageable host memory and is packed into "
+                        "its slot inside the timed region on %d host threads"
+                        % packthreads}
         out["end_to_end_queries_per_s"] = \
             out["mum"]["end_to_end_queries_per_s"]
         return out
@@ -1387,6 +1435,19 @@ def end_to_end(V, index, dg, n, nq, m, L, dev):
     out["reads"] = "two bits per symbol (vsa_pack_reads, %d bytes per read)" \
         % (V.lib.vsa_packed_words(m) * 8)
     out["pack_reads_per_s_one_host_thread"] = packrate[0]
+    # ... and on the host threads of this GPU's share of the box
+    W = int(V.lib.vsa_packed_words(m))
+    scratch, sp = np.zeros(nq * W, np.uint64), np.zeros(1024 * m, np.uint8)
+    best = 0.0
+    for _ in range(3):
+        ns = C.c_uint64(0)
+        t0 = time.perf_counter()
+        V._check(V.lib.vsa_pack_reads_mt(
+            hbatches[0].ctypes.data, nq, m, m, scratch.ctypes.data,
+            sp.ctypes.data, 1024, C.byref(ns), packthreads))
+        best = max(best, nq / (time.perf_counter() - t0))
+    out["pack_reads_per_s"] = {"threads": packthreads, "value": best}
+    del scratch, sp
     out["bytes"] = both(False)
     V.device_free(dq, dev)
     return out

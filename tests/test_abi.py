@@ -116,7 +116,7 @@ def test_pack_reads_is_host_code_and_round_trips(V):
         flagged = np.flatnonzero(r[:, W - 1] & np.uint64(0xFF))
         assert list(flagged) == [7, 90]
         assert np.array_equal(special[:m], sym[7 * m:8 * m])
-        assert int(r[90, 0]) == 1
+        assert int(r[90, 0]) >> 8 == 1 and int(r[7, 0]) >> 8 == 0
         for i in (0, 8, 199):
             got = [(int(r[i, j // 32]) >> (62 - 2 * (j % 32))) & 3
                    for j in range(m)]
@@ -124,6 +124,30 @@ def test_pack_reads_is_host_code_and_round_trips(V):
             # nothing behind the last symbol but the flag byte
             used = 2 * (m - 32 * (W - 1)) if m > 32 * (W - 1) else 0
             assert int(r[i, W - 1]) & ((1 << (64 - used)) - 1) == 0
+    # eight symbols per step (PEXT) == one symbol per step, one thread == three
+    # (the side list is numbered in the order of the reads either way)
+    for m in (5, 29, 100, 150):
+        nq = 200000
+        sym = rng.integers(0, 4, nq * m).astype(np.uint8)
+        for i in (7, 90, 150000, nq - 1):
+            sym[i * m + int(rng.integers(0, m))] = V.WILDCARD
+        os.environ["VSA_PACK_SCALAR"] = "1"
+        try:
+            r0, s0, n0 = V.pack_reads(sym, nq, m)
+        finally:
+            del os.environ["VSA_PACK_SCALAR"]
+        W = int(V.lib.vsa_packed_words(m))
+        assert n0 == 4 and [int(x) >> 8 for x in
+                            r0.reshape(nq, W)[[7, 90, 150000, nq - 1], 0]] == \
+            [0, 1, 2, 3]
+        for threads in (1, 3):
+            r1, s1, n1 = V.pack_reads(sym, nq, m, threads=threads)
+            assert n1 == n0 and np.array_equal(r1, r0) and \
+                np.array_equal(s1, s0), (m, threads)
+    m, nq = 100, 200
+    sym = rng.integers(0, 4, nq * m).astype(np.uint8)
+    sym[7 * m + 50] = sym[90 * m] = V.WILDCARD
+    W = int(V.lib.vsa_packed_words(m))
     # the side list is too small: the reference-style error, nothing silent
     rows = np.zeros(nq * W, np.uint64)
     special = np.zeros(m, np.uint8)

@@ -23,7 +23,7 @@ def unpack(V, rows, special, nq, m):
             np.uint64(3)
     flagged = np.flatnonzero(rows[:, W - 1] & np.uint64(0xFF))
     for i in flagged:
-        k = int(rows[i, 0])
+        k = int(rows[i, 0]) >> 8
         out[i] = special[k * m:(k + 1) * m]
     return out.ravel(), flagged
 

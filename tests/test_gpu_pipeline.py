@@ -88,7 +88,7 @@ def test_slots_are_reused_and_errors_surface_per_batch(V):
         V.Pipeline(gi, 7, 20, 100, 10)
 
 
-def run_packed_job(V, gi, sym, m, mode, L, per):
+def run_packed_job(V, gi, sym, m, mode, L, per, compact=False):
     """the same job through a packed pipeline: the caller packs its reads
     into the slot's page-locked rows (vsa_pack_reads)"""
     nq = len(sym) // m
@@ -109,8 +109,11 @@ def run_packed_job(V, gi, sym, m, mode, L, per):
         out.append(got)
     res = np.concatenate(out) if out else np.zeros(0, V.MATCH_DTYPE)
     if mode == 3:
-        res, st = p.finish()
+        res, st = p.finish(compact=compact)
         assert st.count == len(res)
+        if compact:
+            assert res.dtype == V.MATCH16_DTYPE
+            res = V.expand_match16(res)
     p.close()
     return res
 
@@ -126,6 +129,13 @@ def test_packed_pipeline_gives_the_reference_lists(V, per):
         got = run_packed_job(V, gi, q.symbols, m, mode, L, per)
         assert np.array_equal(H.matches_as_ref(idx, got),
                               H.expected("c1", key)), (per, key)
+    # the MUM list at 16 bytes per match (vsa_pipeline_finish16), and a job
+    # without a MUM
+    got = run_packed_job(V, gi, q.symbols, m, 3, 20, per, compact=True)
+    assert np.array_equal(H.matches_as_ref(idx, got), H.expected("c1", "mum20"))
+    got = run_packed_job(V, gi, np.zeros(64 * m, np.uint8), m, 3, 90, per,
+                         compact=True)
+    assert len(got) == 0
     # reads with wildcards: the side list of every slot, batch after batch
     sym = q.symbols.copy()
     rng = np.random.default_rng(9)

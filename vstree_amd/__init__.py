@@ -39,6 +39,18 @@ NO_SUBST = 0xFFFFFFFF
 
 MATCH_DTYPE = np.dtype([("length", "<u8"), ("dbstart", "<u8"),
                         ("queryseq", "<u8"), ("querystart", "<u8")])
+# vsa_match16: dbstart << 24 | length, queryseq << 16 | querystart
+MATCH16_DTYPE = np.dtype([("dbstart_length", "<u8"),
+                          ("queryseq_querystart", "<u8")])
+
+
+def expand_match16(a):
+    out = np.empty(len(a), MATCH_DTYPE)
+    out["length"] = a["dbstart_length"] & np.uint64(0xFFFFFF)
+    out["dbstart"] = a["dbstart_length"] >> np.uint64(24)
+    out["queryseq"] = a["queryseq_querystart"] >> np.uint64(16)
+    out["querystart"] = a["queryseq_querystart"] & np.uint64(0xFFFF)
+    return out
 
 
 class VsaError(RuntimeError):
@@ -156,6 +168,8 @@ def _load():
         "vsa_pipeline_next": (I, [V, PP, C.POINTER(U64)]),
         "vsa_pipeline_finish": (I, [V, PP, C.POINTER(U64),
                                     C.POINTER(Stats)]),
+        "vsa_pipeline_finish16": (I, [V, PP, C.POINTER(U64),
+                                      C.POINTER(Stats)]),
         "vsa_pipeline_close": (None, [V]),
         "vsa_pipeline_set_offset": (I, [V, U64]),
         "vsa_pipeline_take_candidates": (I, [V, PP, C.POINTER(U64),
@@ -168,6 +182,8 @@ def _load():
         "vsa_queries_from_device": (I, [V, U64, U32, I, PP]),
         "vsa_packed_words": (U32, [U32]),
         "vsa_pack_reads": (I, [V, U64, U32, U64, V, V, U64, C.POINTER(U64)]),
+        "vsa_pack_reads_mt": (I, [V, U64, U32, U64, V, V, U64, C.POINTER(U64),
+                                  U32]),
         "vsa_queries_from_host_packed": (I, [V, U64, U32, V, U64, I, PP]),
         "vsa_queries_reverse_complement": (I, [V, PP]),
         "vsa_queries_free": (None, [V]),
@@ -758,8 +774,19 @@ class Pipeline:
                 MATCH_DTYPE)
         return rc, a.copy() if copy else a
 
-    def finish(self, copy=True):
+    def finish(self, copy=True, compact=False):
+        """compact: vsa_pipeline_finish16 -> an array of MATCH16_DTYPE
+        (expand_match16 gives the records)"""
         ptr, n, st = C.c_void_p(), C.c_uint64(), Stats()
+        if compact:
+            _check(lib.vsa_pipeline_finish16(self._h, C.byref(ptr),
+                                             C.byref(n), C.byref(st)))
+            if n.value == 0:
+                return np.zeros(0, MATCH16_DTYPE), st
+            a = np.ctypeslib.as_array(
+                (C.c_uint64 * (2 * n.value)).from_address(ptr.value)).view(
+                    MATCH16_DTYPE)
+            return (a.copy() if copy else a), st
         _check(lib.vsa_pipeline_finish(self._h, C.byref(ptr), C.byref(n),
                                        C.byref(st)))
         if n.value == 0:
@@ -855,7 +882,7 @@ def synth_queries(genome, nq, m, seed=QUERY_SEED):
     return q
 
 
-def pack_reads(symbols, nq, m, stride=None, specialcap=None):
+def pack_reads(symbols, nq, m, stride=None, specialcap=None, threads=1):
     """-> (rows u64[nq * W], special u8[ns * m], ns)"""
     stride = m if stride is None else stride
     W = int(lib.vsa_packed_words(m))
@@ -863,8 +890,8 @@ def pack_reads(symbols, nq, m, stride=None, specialcap=None):
     cap = nq if specialcap is None else specialcap
     special = np.zeros(max(cap, 1) * m, np.uint8)
     ns = C.c_uint64(0)
-    _check(lib.vsa_pack_reads(_ptr(symbols), nq, m, stride, _ptr(rows),
-                              _ptr(special), cap, C.byref(ns)))
+    _check(lib.vsa_pack_reads_mt(_ptr(symbols), nq, m, stride, _ptr(rows),
+                                 _ptr(special), cap, C.byref(ns), threads))
     return rows, special[:ns.value * m], int(ns.value)
 
 

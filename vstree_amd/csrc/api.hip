@@ -1073,62 +1073,7 @@ extern "C" uint32_t vsa_packed_words(uint32_t querylength)
   return vsa_rowwords(querylength);
 }
 
-// One row per read, see include/vstree_amd.h.  Host code: the caller's reader
-// runs it while it parses (several threads over disjoint reads).
-extern "C" int vsa_pack_reads(const uint8_t *symbols, uint64_t numofqueries,
-                              uint32_t querylength, uint64_t stride,
-                              uint64_t *rows, uint8_t *special,
-                              uint64_t specialcapacity,
-                              uint64_t *numofspecial)
-{
-  if ((numofqueries > 0 && (symbols == nullptr || rows == nullptr)) ||
-      numofspecial == nullptr || querylength == 0 ||
-      (specialcapacity > 0 && special == nullptr))
-  {
-    VSA_ERROR("vsa_pack_reads: bad argument");
-    return -1;
-  }
-  const uint32_t m = querylength, W = vsa_rowwords(m);
-  uint64_t ns = *numofspecial;
-  for (uint64_t i = 0; i < numofqueries; i++)
-  {
-    const uint8_t *r = symbols + i * stride;
-    uint64_t *row = rows + i * W;
-    uint8_t bad = 0;
-    for (uint32_t w = 0; w < W; w++)
-    {
-      uint64_t acc = 0;
-      const uint32_t lo = 32 * w, hi = lo + 32 < m ? lo + 32 : m;
-      for (uint32_t j = lo; j < hi; j++)
-      {
-        const uint8_t c = r[j];
-        bad |= c;
-        acc |= (uint64_t) (c & 3u) << (62 - 2 * (j - lo));
-      }
-      row[w] = acc;
-    }
-    if (bad > 3)
-    {
-      // a symbol that is no base (a wildcard; in a Multiseq also a
-      // separator would be): the read travels as bytes
-      if (ns >= specialcapacity)
-      {
-        VSA_ERROR("vsa_pack_reads: more than %lu reads with a special symbol",
-                  (unsigned long) specialcapacity);
-        return -2;
-      }
-      memcpy(special + ns * m, r, m);
-      for (uint32_t w = 0; w < W; w++)
-      {
-        row[w] = 0;
-      }
-      row[0] = ns++;
-      row[W - 1] |= 1u;
-    }
-  }
-  *numofspecial = ns;
-  return 0;
-}
+// (vsa_pack_reads, vsa_pack_reads_mt: pack_reads.c -- host code, no GPU)
 
 __global__ void __launch_bounds__(256)
 k_unpack_rows(const uint64_t *__restrict__ rows, uint32_t W,
@@ -1144,7 +1089,8 @@ k_unpack_rows(const uint64_t *__restrict__ rows, uint32_t W,
   }
   const uint64_t *row = rows + q * W;
   const bool flagged = (row[W - 1] & 0xFFu) != 0 && nside > 0;
-  const uint64_t k = flagged ? (row[0] < nside ? row[0] : nside - 1) : 0;
+  const uint64_t k0 = row[0] >> 8,
+                 k = flagged ? (k0 < nside ? k0 : nside - 1) : 0;
   const uint8_t *sym = flagged ? side + k * (uint64_t) m : nullptr;
   for (uint32_t j = lane; j < m; j += 64)
   {
@@ -1213,11 +1159,11 @@ extern "C" int vsa_queries_from_host_packed(const uint64_t *rows,
   for (uint64_t i = 0; i < numofqueries; i++)
   {
     const uint64_t *row = rows + i * W;
-    if ((row[W - 1] & 0xFFu) != 0 && row[0] >= numofspecial)
+    if ((row[W - 1] & 0xFFu) != 0 && (row[0] >> 8) >= numofspecial)
     {
       VSA_ERROR("vsa_queries_from_host_packed: read %lu names entry %lu of a "
                 "side list of %lu reads", (unsigned long) i,
-                (unsigned long) row[0], (unsigned long) numofspecial);
+                (unsigned long) (row[0] >> 8), (unsigned long) numofspecial);
       return -2;
     }
   }

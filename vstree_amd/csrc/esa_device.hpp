@@ -544,7 +544,7 @@ __device__ __forceinline__ void vsa_pq_from_row(const DevQueries &qs,
   {
     // (the index is clamped to the list: a row that lies reads another read,
     // never another buffer)
-    const uint64_t k = a.lo < qs.nside ? a.lo : qs.nside - 1;
+    const uint64_t k = (a.lo >> 8) < qs.nside ? (a.lo >> 8) : qs.nside - 1;
     const uint8_t *sym = qs.side + k * (uint64_t) m;
     uint32_t firstbad = m;
     src.bytes = sym;
@@ -609,7 +609,8 @@ __device__ __forceinline__ bool vsa_row_of(const DevQueries &qs, uint64_t q,
   const bool flagged = (rq.row[W - 1] & 0xFFu) != 0 && qs.nside > 0;
   if (flagged)
   {
-    const uint64_t k = rq.row[0] < qs.nside ? rq.row[0] : qs.nside - 1;
+    const uint64_t k0 = rq.row[0] >> 8,
+                   k = k0 < qs.nside ? k0 : qs.nside - 1;
     src.bytes = qs.side + k * (uint64_t) m;
   }
   return flagged;

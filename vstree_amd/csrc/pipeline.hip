@@ -618,11 +618,30 @@ extern "C" int vsa_pipeline_next(vsa_pipeline *p, const vsa_match **matches,
   return s.rc;
 }
 
+namespace
+{
+
+// records -> 16 bytes each (vsa_match16, include/vstree_amd.h)
+__global__ void k_compact_records(const vsa_match *__restrict__ in, uint64_t n,
+                                  vsa_match16 *__restrict__ out)
+{
+  const uint64_t i = vsa_bid() * blockDim.x + threadIdx.x;
+  if (i < n)
+  {
+    const vsa_match m = in[i];
+    vsa_match16 c;
+    c.dbstart_length = (m.dbstart << 24) | (m.length & 0xFFFFFFu);
+    c.queryseq_querystart = (m.queryseq << 16) | (m.querystart & 0xFFFFu);
+    out[i] = c;
+  }
+}
+
 // -mum: the filter over the candidates of ALL batches submitted so far (the
 // batches must have been taken with vsa_pipeline_next); MUMs in host memory,
 // ascending dbstart, valid until the pipeline is closed or finished again.
-extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
-                                   uint64_t *count, vsa_stats *stats)
+// compact: 16 bytes per MUM instead of 32 over the host link.
+int pipeline_finish(vsa_pipeline *p, bool compact, const void **matches,
+                    uint64_t *count, vsa_stats *stats)
 {
   if (p == nullptr || matches == nullptr || count == nullptr || p->mode != 3)
   {
@@ -658,6 +677,13 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
   {
     return -100;
   }
+  if (compact && (p->m > 0xFFFFu || (p->index->n >> 40) != 0))
+  {
+    VSA_ERROR("vsa_pipeline_finish16: reads of %u symbols on a text of %lu: "
+              "a match does not fit 16 bytes", p->m,
+              (unsigned long) p->index->n);
+    return -1;
+  }
   vsa_result *res = nullptr;
   const int rc = vsa_mumuniqueinquery_range_packed(
       p->rows, p->nrows, p->lengthbits, p->index->n, p->index->device, 0,
@@ -670,7 +696,7 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
   }
   const uint64_t c = vsa_result_count(res);
   int out = 0;
-  if (c > p->hostmumscap)
+  if (c * (compact ? 16 : 32) > p->hostmumscap * 32)
   {
     // page-locking costs about a third of a second per GB: the buffer is
     // kept for the next job
@@ -679,7 +705,7 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
       (void) hipHostFree(p->hostmums);
       p->hostmums = nullptr;
     }
-    p->hostmumscap = c + c / 8 + 1024;
+    p->hostmumscap = (c + c / 8 + 1024) / (compact ? 2 : 1) + 1;
     if (hipHostMalloc((void **) &p->hostmums,
                       p->hostmumscap * sizeof(vsa_match),
                       hipHostMallocDefault) != hipSuccess)
@@ -691,9 +717,33 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
       out = -100;
     }
   }
-  if (out == 0 && c > 0 && vsa_result_fetch(res, p->hostmums, c) != 0)
+  if (out == 0 && c > 0 && !compact &&
+      vsa_result_fetch(res, p->hostmums, c) != 0)
   {
     out = -100;
+  }
+  if (out == 0 && c > 0 && compact)
+  {
+    void *small = nullptr;
+    if (vsa_dev_alloc(&small, c * sizeof(vsa_match16)) != 0)
+    {
+      out = -100;
+    } else
+    {
+      k_compact_records<<<vsa_grid((c + 255) / 256), 256, 0, p->down>>>(
+          res->matches, c, (vsa_match16 *) small);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(p->hostmums, small, c * sizeof(vsa_match16),
+                         hipMemcpyDeviceToHost, p->down) != hipSuccess ||
+          hipStreamSynchronize(p->down) != hipSuccess)
+      {
+        (void) hipGetLastError();
+        VSA_ERROR("vsa_pipeline_finish16: copy of %lu MUMs to the host failed",
+                  (unsigned long) c);
+        out = -100;
+      }
+      vsa_dev_free(small);
+    }
   }
   if (stats != nullptr)
   {
@@ -709,6 +759,21 @@ extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
   p->nrows = 0; // the next job starts afresh
   p->candidates = 0;
   return out;
+}
+
+} // namespace
+
+extern "C" int vsa_pipeline_finish(vsa_pipeline *p, const vsa_match **matches,
+                                   uint64_t *count, vsa_stats *stats)
+{
+  return pipeline_finish(p, false, (const void **) matches, count, stats);
+}
+
+extern "C" int vsa_pipeline_finish16(vsa_pipeline *p,
+                                     const vsa_match16 **matches,
+                                     uint64_t *count, vsa_stats *stats)
+{
+  return pipeline_finish(p, true, (const void **) matches, count, stats);
 }
 
 // ---- for a caller that runs one pipeline per GPU (multi_gpu.cpp) ----------
