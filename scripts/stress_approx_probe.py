@@ -2,7 +2,8 @@
 """Randomised GPU-vs-oracle comparison of approximate complete matching
 (-complete -e K | -h K): texts with planted repeats (queries with hundreds of
 piece hits), wildcards and several sequences; uniform and mixed read lengths,
-small and large batches (the per-length plan), thresholds 1..3.
+small and large batches (the per-length plan), thresholds 1..3, and the
+best-of form (Kb) on the same batch.
 usage: stress_approx_probe.py [ROUNDS] [SEED]"""
 import os
 import sys
@@ -87,9 +88,33 @@ for rnd in range(rounds):
                  len(want)), flush=True)
         sys.exit(1)
     checked += 1
-    print("round %d ok: %s k=%d m~%d %s %d reads, %d matches, %.0f s" % (
-        rnd, "edist" if doedist else "hamming", k, m0,
-        "uniform" if uniform else "ragged", nreads, len(want),
-        time.time() - t0), flush=True)
+    # the best-of form on the same batch (-e Kb / -h Kb: the matches at the
+    # read's smallest distance within K percent of its length)
+    kb, nbest = int(rng.integers(1, 10)), -1
+    try:
+        wantb = H.oracle_approx(host, hq, doedist, kb, percent=2)
+    except (H.OracleNotCovered, H.OracleError):
+        wantb = None
+    if wantb is not None:
+        try:
+            gotb = V.findapproxcompletematches(gi, gq, doedist, kb, 2).fetch()
+        except V.VsaError as e:
+            if e.code != V.NOT_COVERED:
+                raise
+            gotb = None
+        if gotb is not None:
+            if not np.array_equal(gotb, wantb):
+                print("MISMATCH round %d (best of): %s %db m0=%d %s %d reads: "
+                      "gpu %d oracle %d"
+                      % (rnd, "edist" if doedist else "hamming", kb, m0,
+                         "uniform" if uniform else "ragged", nreads,
+                         len(gotb), len(wantb)), flush=True)
+                sys.exit(1)
+            checked += 1
+            nbest = len(wantb)
+    print("round %d ok: %s k=%d m~%d %s %d reads, %d matches; %db: %d, %.0f s"
+          % (rnd, "edist" if doedist else "hamming", k, m0,
+             "uniform" if uniform else "ragged", nreads, len(want), kb, nbest,
+             time.time() - t0), flush=True)
 print("all %d lists equal the oracle's (%d configurations outside the "
       "restatement)" % (checked, declined))
