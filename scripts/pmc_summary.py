@@ -124,9 +124,9 @@ def main():
             # WRITE_SIZE) KiB per launch (see the note above)
             fams = {}
             for key, pattern, factor in (
-                    ("k_mum_first", "k_mum_first<unsigned int, true", 2),
-                    ("k_mum_plan", "k_mum_plan<unsigned int, true", 2),
-                    ("k_complete_search", "k_complete_search<unsigned int, true, true", 2),
+                    ("k_mum_first", "k_mum_first<unsigned int, true, true, true", 2),
+                    ("k_mum_plan", "k_mum_plan<unsigned int, true, true, true", 2),
+                    ("k_complete_search", "k_complete_search<unsigned int, true, true, true", 2),
                     ("k_query_search_mem", "k_query_search_planned<unsigned int, 256, true, false, false", 2),
                     ("k_mem_plan", "k_mem_plan", 2),
                     ("k_apm_banded", "k_apm_banded", 2),
