@@ -91,22 +91,33 @@ for rnd in range(rounds):
                  not (r == H.SEPARATOR).any()]
     hq = H.Queries.from_list(reads)
     gq = V.Queries.from_host(hq.symbols, hq.start, hq.length)
+    # batches of one length also as rows of two bits per symbol (reads with a
+    # wildcard on the side list)
+    forms = [("bytes", gq)]
+    if uniform and hq.nq > 0:
+        # (a Multiseq: a separator between two reads, stride m + 1)
+        forms.append(("rows", V.Queries.from_host_packed(hq.symbols, m0,
+                                                         stride=m0 + 1)))
     pl = gi.info().prefixlength
     lo = max(pl, 6)     # below that every offset matches thousands of suffixes
     for L in sorted({lo, int(rng.integers(lo, 40)), 20}):
         for kw, sp in (({}, 0), ({}, 2), (dict(mum=True, cand=True), 2),
                        (dict(mum=True), 0)):
-            got = V.findquerymatches(gi, gq, L, speedup=sp, **kw).fetch()
             want = H.oracle_querymatches(host, hq, L, speedup=sp, **kw)
-            if not np.array_equal(got, want):
-                print("MISMATCH round %d L %d %s sp %d: gpu %d oracle %d" % (
-                    rnd, L, kw, sp, len(got), len(want)), flush=True)
-                sys.exit(1)
-            checked += 1
+            for form, q_ in forms:
+                got = V.findquerymatches(gi, q_, L, speedup=sp, **kw).fetch()
+                if not np.array_equal(got, want):
+                    print("MISMATCH round %d L %d %s sp %d (%s): gpu %d "
+                          "oracle %d" % (rnd, L, kw, sp, form, len(got),
+                                         len(want)), flush=True)
+                    sys.exit(1)
+                checked += 1
     if hq.length.min() >= pl:
-        got = V.findcompletematches(gi, gq).fetch()
-        assert np.array_equal(got, H.oracle_complete(host, hq)), rnd
-        checked += 1
+        want = H.oracle_complete(host, hq)
+        for form, q_ in forms:
+            got = V.findcompletematches(gi, q_).fetch()
+            assert np.array_equal(got, want), (rnd, form)
+            checked += 1
     print("round %d ok: %d sequences, %d bp, %d reads (%s), %.0f s" % (
         rnd, nseq, len(tis), len(reads), "uniform" if uniform else "ragged",
         time.time() - t0), flush=True)
