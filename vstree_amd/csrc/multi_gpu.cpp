@@ -182,6 +182,39 @@ bool distinct(const std::vector<int> &d)
   return std::adjacent_find(s.begin(), s.end()) == s.end();
 }
 
+// Peer copies (the index to its replicas, candidate rows between replicas)
+// go straight over xGMI where the devices can map each other's memory; where
+// they cannot, or the switch says no, the runtime stages them.  Failures are
+// not errors here.
+void allowpeers(const std::vector<int> &dev)
+{
+  const char *off = getenv("VSA_MULTI_PEER_ACCESS");
+  if (off != nullptr && strcmp(off, "0") == 0)
+  {
+    return;
+  }
+  for (size_t r = 0; r < dev.size(); r++)
+  {
+    if (hipSetDevice(dev[r]) != hipSuccess)
+    {
+      (void) hipGetLastError();
+      continue;
+    }
+    for (size_t s = 0; s < dev.size(); s++)
+    {
+      int can = 0;
+      if (dev[s] == dev[r] ||
+          hipDeviceCanAccessPeer(&can, dev[r], dev[s]) != hipSuccess || !can)
+      {
+        (void) hipGetLastError();
+        continue;
+      }
+      (void) hipDeviceEnablePeerAccess(dev[s], 0); // (again: already enabled)
+      (void) hipGetLastError();
+    }
+  }
+}
+
 // RCCL communicators for the counter reduction: one per replica, all in this
 // process.  Replicas that share a device (tests on a one-GPU box) cannot form
 // a communicator; their counters are summed on the host.
@@ -599,6 +632,8 @@ extern "C" int vsa_multi_replicate(vsa_index *first, const int *devices,
   m->ix[0] = first;
   std::vector<int> rcs(ndevices, 0);
   std::vector<std::string> msgs(ndevices);
+  allowpeers(m->dev);
+  (void) hipSetDevice(m->dev[0]);
   // every other replica pulls its copy from replica 0 at the same time: the
   // GPUs of a node are connected pairwise, each copy has a link of its own
   onallreplicas(ndevices, [&](uint32_t r) {
