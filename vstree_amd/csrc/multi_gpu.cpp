@@ -155,6 +155,10 @@ struct Exchange
   uint64_t rowcap = 0, recvcap = 0;
   uint64_t *devmeta = nullptr, *hostmeta = nullptr;
   hipStream_t copy = nullptr;
+  // one stream per replica the rows are pulled from: every pair of GPUs has
+  // an xGMI link of its own, and copies queued on one stream would use them
+  // one after the other
+  std::vector<hipStream_t> from;
 };
 
 } // namespace
@@ -708,6 +712,13 @@ extern "C" void vsa_multi_close(vsa_multi *m)
     {
       (void) hipStreamDestroy(x.copy);
     }
+    for (hipStream_t st : x.from)
+    {
+      if (st != nullptr)
+      {
+        (void) hipStreamDestroy(st);
+      }
+    }
   }
   for (size_t r = 0; r < m->comms.size(); r++)
   {
@@ -1163,6 +1174,10 @@ void devicefilter(const DeviceJob &job, uint32_t r,
   }
   uint64_t at = 0;
   bool ok = true;
+  if (x.from.size() != world)
+  {
+    x.from.assign(world, nullptr);
+  }
   for (uint32_t s = 0; s < world && ok; s++)
   {
     if (s == r)
@@ -1178,13 +1193,25 @@ void devicefilter(const DeviceJob &job, uint32_t r,
     const uint64_t c = meta[r];
     if (c > 0)
     {
-      ok = hipMemcpyPeerAsync((char *) x.recv + at * 16, m->dev[r],
+      if (x.from[s] == nullptr)
+      {
+        ok = hipStreamCreateWithFlags(&x.from[s], hipStreamNonBlocking) ==
+             hipSuccess;
+      }
+      ok = ok &&
+           hipMemcpyPeerAsync((char *) x.recv + at * 16, m->dev[r],
                               (const char *) m->xch[s].rows + before * 16,
-                              m->dev[s], c * 16, x.copy) == hipSuccess;
+                              m->dev[s], c * 16, x.from[s]) == hipSuccess;
       at += c;
     }
   }
-  ok = ok && hipStreamSynchronize(x.copy) == hipSuccess;
+  for (uint32_t s = 0; s < world; s++)
+  {
+    if (x.from[s] != nullptr)
+    {
+      ok = hipStreamSynchronize(x.from[s]) == hipSuccess && ok;
+    }
+  }
   if (!ok)
   {
     (void) fail(o, -100, "vsa_multi: peer copy of MUM candidates failed");
