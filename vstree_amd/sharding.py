@@ -82,6 +82,17 @@ def global_mum_filter(dist, torch, local_candidates, device, filter_fn):
     return nmum, sumlen, sum(counts)
 
 
+def _no_device_rows_through_the_gather(rows):
+    """the gather-everything form moves world times the rows: it is the form
+    of the CPU tests and of the one-GPU rehearsal (host copies), never a
+    silent fallback for rows that live on a GPU"""
+    if getattr(rows, "is_cuda", False):
+        raise RuntimeError(
+            "vstree_amd.sharding: device rows, but the process group is not "
+            "on RCCL (backend %r): the exchange would gather every rank's "
+            "rows on every rank" % (rows.device,))
+
+
 def _exchange_rows(dist, torch, rows, dest, device):
     """rows [N,4] int64 -> the rows every rank addressed to this rank
     (dest[i] = receiving rank), concatenated in rank order"""
@@ -99,6 +110,7 @@ def _exchange_rows(dist, torch, rows, dest, device):
     else:
         # backend without all-to-all (gloo in the CPU tests): gather all,
         # keep what is addressed to this rank
+        _no_device_rows_through_the_gather(rows)
         parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device)
         dests, _ = all_gather_matches(
             dist, torch,
@@ -229,6 +241,7 @@ def partitioned_mum_filter_presorted(dist, torch, rows, send, maxright,
     else:
         # backend without all-to-all (gloo in the CPU tests): gather all,
         # cut out what is addressed to this rank
+        _no_device_rows_through_the_gather(rows)
         parts, _ = all_gather_matches(dist, torch, rows.reshape(-1), device,
                                       words)
         keep = []
