@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Registers, LDS and scratch of every kernel in a HIP object or library.
 
-    python scripts/kernel_resources.py vstree_amd/_build/esa_search.o [pattern]
+    make -C vstree_amd/csrc COMPRESS= OBJDIR=/tmp/vsa_plain /tmp/vsa_plain/esa_search.o
+    python scripts/kernel_resources.py /tmp/vsa_plain/esa_search.o [pattern]
+
+(the library's own objects are built with --offload-compress; the variant of
+the compressed bundle hipcc 7.2 writes is not one this script unpacks)
 
 Finds the clang offload bundles in the file, takes the gfx950 code objects out
 and reads their metadata notes with llvm-readelf.  (Bundles may be compressed
