@@ -154,7 +154,6 @@ struct Exchange
   void *rows = nullptr, *recv = nullptr;
   uint64_t rowcap = 0, recvcap = 0;
   uint64_t *devmeta = nullptr, *hostmeta = nullptr;
-  hipStream_t copy = nullptr;
   // one stream per replica the rows are pulled from: every pair of GPUs has
   // an xGMI link of its own, and copies queued on one stream would use them
   // one after the other
@@ -708,10 +707,6 @@ extern "C" void vsa_multi_close(vsa_multi *m)
     {
       (void) hipHostFree(x.hostmeta);
     }
-    if (x.copy != nullptr)
-    {
-      (void) hipStreamDestroy(x.copy);
-    }
     for (hipStream_t st : x.from)
     {
       if (st != nullptr)
@@ -1077,9 +1072,7 @@ void devicesearch(const DeviceJob &job, uint32_t r, DeviceOut &o)
           (vsa_device_malloc(2 * (uint64_t) world * 8, m->dev[r],
                              (void **) &x.devmeta) != 0 ||
            hipHostMalloc((void **) &x.hostmeta, 2 * (size_t) world * 8,
-                         hipHostMallocDefault) != hipSuccess ||
-           hipStreamCreateWithFlags(&x.copy, hipStreamNonBlocking) !=
-               hipSuccess))
+                         hipHostMallocDefault) != hipSuccess))
       {
         (void) fail(o, -100, "vsa_multi: no memory for the exchange state");
         return;
@@ -1575,9 +1568,7 @@ extern "C" int vsa_multi_pipeline_finish(vsa_multi_pipeline *p,
         (vsa_device_malloc(2 * (uint64_t) world * 8, m->dev[r],
                            (void **) &x.devmeta) != 0 ||
          hipHostMalloc((void **) &x.hostmeta, 2 * (size_t) world * 8,
-                       hipHostMallocDefault) != hipSuccess ||
-         hipStreamCreateWithFlags(&x.copy, hipStreamNonBlocking) !=
-             hipSuccess))
+                       hipHostMallocDefault) != hipSuccess))
     {
       (void) fail(o, -100, "vsa_multi: no memory for the exchange state");
       return;
