@@ -656,50 +656,57 @@ def c_path_mode(a, jsonfd, rank, world):
     if a.host:
         out["bytes_over_pcie_per_step"] = int(nq * N * m + 16 * nq * N +
                                               32 * int(st.count))
+    borrowed = None
     if not a.quick:
-        # the kernel's algorithmic bytes, counted like the N = 1 line does: on
-        # the searches the plans of block 0 hold (test infrastructure: the
-        # instrumented CPU restatement), x the searches of one replica
-        import helpers as H
-        w = info.device_integersize // 8
-        # (replica 0, borrowed: the set owns it)
-        index = V.Index(C.c_void_p(M.lib.vsa_multi_index(multi._h, 0)))
-        t = index.download()
-        host = H.Index(n, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
-                       t["llv"], t["bck"], t["bwt"], None)
-        ns = min(nq, 20000)
-        rows = t["tis"][pos[:ns, None].astype(np.int64) +
-                        np.arange(m)[None, :]].astype(np.uint8)
-        hit = np.flatnonzero(sub[:ns] != V.NO_SUBST)
-        rows[hit, sub[hit]] = (rows[hit, sub[hit]] + step[hit]) & 3
-        small = H.Queries.uniform(np.ascontiguousarray(rows).ravel(), m)
-        block0 = V.Queries.from_host_packed(small.symbols, m, devices[0]) \
-            if a.reads == "packed" else V.Queries.from_host(
-                small.symbols, small.start, small.length, devices[0])
-        per, items = counted_search_bytes(a, V, H, index, block0, host, small,
-                                          m, L, w)
-        block0.close()
-        index._h = None
-        del t, host
-        if per is not None:
-            rf = out["roofline"]
-            nbytes = per * rf["searches_per_launch"]
-            rf.update({
-                "algorithmic_bytes_per_launch": nbytes,
-                "bytes_per_search": per, "searches_counted": items,
-                "bytes_are": "counted",
-                "achieved": nbytes / (kms * 1e-3) / 1e9,
-                "frac": nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "slowest replica per step (HIP events); algorithmic "
-                        "bytes = SURVEY 8d formula counted by the "
-                        "instrumented CPU restatement on the searches the "
-                        "plans of the first %d reads hold, x the searches of "
-                        "one replica" % small.nq})
-            tj = pmc_traffic(n, nq)
-            if tj.get("hbm_bytes_per_launch"):
-                rf["traffic"] = tj["hbm_bytes_per_launch"]
-                rf["traffic_source"] = "%s (the same kernel at N = 1)" % \
-                    tj.get("source")
+        try:
+            # the kernel's algorithmic bytes, counted like the N = 1 line does: on
+            # the searches the plans of block 0 hold (test infrastructure: the
+            # instrumented CPU restatement), x the searches of one replica
+            import helpers as H
+            w = info.device_integersize // 8
+            # (replica 0, borrowed: the set owns it)
+            index = borrowed = V.Index(
+                C.c_void_p(M.lib.vsa_multi_index(multi._h, 0)))
+            t = index.download()
+            host = H.Index(n, info.prefixlength, 4, t["tis"], t["suf"], t["lcp"],
+                           t["llv"], t["bck"], t["bwt"], None)
+            ns = min(nq, 20000)
+            rows = t["tis"][pos[:ns, None].astype(np.int64) +
+                            np.arange(m)[None, :]].astype(np.uint8)
+            hit = np.flatnonzero(sub[:ns] != V.NO_SUBST)
+            rows[hit, sub[hit]] = (rows[hit, sub[hit]] + step[hit]) & 3
+            small = H.Queries.uniform(np.ascontiguousarray(rows).ravel(), m)
+            block0 = V.Queries.from_host_packed(small.symbols, m, devices[0]) \
+                if a.reads == "packed" else V.Queries.from_host(
+                    small.symbols, small.start, small.length, devices[0])
+            per, items = counted_search_bytes(a, V, H, index, block0, host, small,
+                                              m, L, w)
+            block0.close()
+            del t, host
+            if per is not None:
+                rf = out["roofline"]
+                nbytes = per * rf["searches_per_launch"]
+                rf.update({
+                    "algorithmic_bytes_per_launch": nbytes,
+                    "bytes_per_search": per, "searches_counted": items,
+                    "bytes_are": "counted",
+                    "achieved": nbytes / (kms * 1e-3) / 1e9,
+                    "frac": nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "slowest replica per step (HIP events); algorithmic "
+                            "bytes = SURVEY 8d formula counted by the "
+                            "instrumented CPU restatement on the searches the "
+                            "plans of the first %d reads hold, x the searches of "
+                            "one replica" % small.nq})
+                tj = pmc_traffic(n, nq)
+                if tj.get("hbm_bytes_per_launch"):
+                    rf["traffic"] = tj["hbm_bytes_per_launch"]
+                    rf["traffic_source"] = "%s (the same kernel at N = 1)" % \
+                        tj.get("source")
+        except Exception as e:     # the roofline must not sink the line
+            log("bench.py: counting the kernel's bytes failed: %r" % (e,))
+        finally:
+            if borrowed is not None:
+                borrowed._h = None     # (not ours to close)
     if mp is not None:
         mp.close()
     multi.close()
