@@ -676,6 +676,9 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // MUM modes: first pass + work plan (mum_workplan.inc)
   DevBuf wcount, wtemp, wplan, wlist, wfirste, wfmlen, wfmdb, wboffset;
   uint64_t nfirstpass = 0; // candidates of the first pass (k_append_first)
+  // reads the first pass left to the plan (low half) | first-pass candidates
+  // (high half), on the device
+  const uint64_t *nlistword = nullptr;
   uint64_t plansearches = 0, nfirst = 0, mumsum = ~0ull;
   // -mum with the filter: candidates as (sort key, value) pairs, see
   // mumfilter_packed
@@ -889,7 +892,6 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     // the reads the first pass has not finished, as a list (counts per
     // workgroup, a scan over the workgroups, an ordered fill); with it come
     // the places of the first pass's candidates
-    uint64_t nlist = 0;
     size_t tb = 0;
     {
       // (queries < 2^32: the condition of this branch)
@@ -921,16 +923,12 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           wcount.as<uint32_t>(), nq, 0u, wboffset.as<uint64_t>(),
           wlist.as<uint32_t>());
       VSA_HIP(hipGetLastError());
-      const Fetch f = {wboffset.as<uint64_t>() + nb, 8};
-      uint64_t both = 0;
-      if (fetchwords(stream, &f, 1, &both))
-      {
-        return -100;
-      }
-      nlist = both & 0xFFFFFFFFull;
-      nfirstpass = both >> 32;
+      // (the length of the list and the number of first-pass candidates,
+      // wboffset[nb], come to the host with the counts behind the search
+      // kernel: no wait here -- the plan kernel is launched over all reads
+      // and reads the length on the device)
+      nlistword = wboffset.as<uint64_t>() + nb;
     }
-    if (nlist > 0)
     {
       // on the deep tables the plan answers the offsets it locates itself
       // (PlanEmit)
@@ -938,7 +936,8 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       if (planemit)
       {
         // room for every search A of the workgroups that share a region
-        const uint64_t nb = blocksfor(nlist),
+        // (sized for a list of all reads: its length is not known here)
+        const uint64_t nb = blocksfor(nq),
                        pershard = (nb + nshards - 1) / nshards;
         pcap = pershard * VSA_BLOCK * (VSA_PLAN_ROUNDS - 1);
         if (pcursor.alloc((size_t) nshards * VSA_CURSOR_STRIDE * 8) ||
@@ -964,15 +963,15 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
         if (rows)
         {
           k_mum_plan<IDX, true, true, true>
-              <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-                  ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+              <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+                  ix, qs, wlist.as<uint32_t>(), nlistword, searchlength,
                   wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
                   wplan.as<PlanRanges>(), em);
         } else
         {
           k_mum_plan<IDX, true, true>
-              <<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-                  ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+              <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+                  ix, qs, wlist.as<uint32_t>(), nlistword, searchlength,
                   wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
                   wplan.as<PlanRanges>(), em);
         }
@@ -981,14 +980,13 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
                               stream));
       } else
       {
-        k_mum_plan<IDX, false><<<gridfor(nlist), VSA_BLOCK, 0, stream>>>(
-            ix, qs, wlist.as<uint32_t>(), nlist, searchlength,
+        k_mum_plan<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+            ix, qs, wlist.as<uint32_t>(), nlistword, searchlength,
             wfirste.as<uint32_t>(), wcount.as<uint32_t>(),
             wplan.as<PlanRanges>());
       }
       VSA_HIP(hipGetLastError());
     }
-    plansearches = 2 * nlist;
     if (const char *pf = getenv("VSA_DEBUG_PLANFILE"))
     {
       // the plans of the first 65 536 queries as they stand when the search
@@ -1135,16 +1133,23 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
                           doff.as<uint64_t>(), summary.as<uint64_t>(),
                           stream));
     {
-      const Fetch f[6] = {{summary.as<uint64_t>(), 8},
+      const Fetch f[7] = {{summary.as<uint64_t>(), 8},
                           {summary.as<uint64_t>() + 1, 8},
                           {summary.as<uint64_t>() + 2, 8},
                           {summary.as<uint64_t>() + 3, 8},
                           {summary.as<uint64_t>() + 4, 8},
-                          {planemit ? psummary.p : summary.p, 8}};
-      uint64_t got[6];
-      if (fetchwords(stream, f, 6, got))
+                          {planemit ? psummary.p : summary.p, 8},
+                          {nlistword != nullptr ? (const void *) nlistword
+                                                : summary.p, 8}};
+      uint64_t got[7];
+      if (fetchwords(stream, f, 7, got))
       {
         return -100;
+      }
+      if (nlistword != nullptr)
+      {
+        nfirstpass = got[6] >> 32;
+        plansearches = 2 * (got[6] & 0xFFFFFFFFull);
       }
       nplan = planemit ? got[5] : 0;
       needed = got[0];
