@@ -786,7 +786,15 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     {
       const bool staged = qs.dense != 0 && qs.uniformlen <= 128 &&
                           (qs.uniformlen & 3u) == 0;
-      if (staged)
+      if (queries->rows != nullptr && queries->roww <= 4)
+      {
+        // (a packed batch: offset 0 of every read from its row, as -mum does)
+        k_mum_first<IDX, true, true, true>
+            <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+                ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+                wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+                wfmdb.as<uint64_t>());
+      } else if (staged)
       {
         k_mum_first<IDX, true, true>
             <<<gridfor(nq), VSA_BLOCK, (size_t) VSA_BLOCK * qs.uniformlen,
