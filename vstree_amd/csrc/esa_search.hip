@@ -860,6 +860,17 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       return -100;
     }
     VSA_HIP(hipMemsetAsync(wcount.as<uint32_t>() + nq, 0, 4, stream));
+    // per workgroup of the first pass: reads it leaves to the plan | reads
+    // whose offset 0 is a candidate (counted by the first pass itself)
+    // (queries < 2^32: the condition of this branch)
+    const uint64_t nb = blocksfor(nq), nbr = vsa_grid_blocks(nb);
+    DevBuf bcount;
+    if (bcount.alloc((nbr + 1) * 8) || wboffset.alloc((nbr + 1) * 8))
+    {
+      return -100;
+    }
+    // (both halves of a count stay below 2^32: nq does)
+    VSA_HIP(hipMemsetAsync(bcount.as<uint64_t>() + nb, 0, 8, stream));
     tfirst.start();
     if (rows)
     {
@@ -867,7 +878,7 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
           <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
               ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
               wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
-              wfmdb.as<uint64_t>());
+              wfmdb.as<uint64_t>(), bcount.as<uint64_t>());
     } else if (deepok)
     {
       // reads of one length m (a multiple of 4, <= 128), back to back:
@@ -880,41 +891,29 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
             <<<gridfor(nq), VSA_BLOCK, (size_t) VSA_BLOCK * qs.uniformlen,
                stream>>>(ix, qs, perquery, searchlength,
                          wcount.as<uint32_t>(), wfirste.as<uint32_t>(),
-                         wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>());
+                         wfmlen.as<uint32_t>(), wfmdb.as<uint64_t>(),
+                         bcount.as<uint64_t>());
       } else
       {
         k_mum_first<IDX, true><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
             ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
             wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
-            wfmdb.as<uint64_t>());
+            wfmdb.as<uint64_t>(), bcount.as<uint64_t>());
       }
     } else
     {
       k_mum_first<IDX, false><<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
           ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
           wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
-          wfmdb.as<uint64_t>());
+          wfmdb.as<uint64_t>(), bcount.as<uint64_t>());
     }
     tfirst.stop();
     VSA_HIP(hipGetLastError());
-    // the reads the first pass has not finished, as a list (counts per
+    // the reads the first pass has not finished, as a list (its counts per
     // workgroup, a scan over the workgroups, an ordered fill); with it come
     // the places of the first pass's candidates
     size_t tb = 0;
     {
-      // (queries < 2^32: the condition of this branch)
-      const uint64_t nb = blocksfor(nq), nbr = vsa_grid_blocks(nb);
-      DevBuf bcount;
-      if (bcount.alloc((nbr + 1) * 8) || wboffset.alloc((nbr + 1) * 8))
-      {
-        return -100;
-      }
-      // (both halves of a count stay below 2^32: nq does)
-      VSA_HIP(hipMemsetAsync(bcount.as<uint64_t>() + nb, 0, 8, stream));
-      k_wanted_count<<<vsa_grid(nb), VSA_BLOCK, 0, stream>>>(
-          wcount.as<uint32_t>(), nq, 0u, wfmlen.as<uint32_t>(),
-          bcount.as<uint64_t>());
-      VSA_HIP(hipGetLastError());
       VSA_HIP(rocprim::exclusive_scan(nullptr, tb, bcount.as<uint64_t>(),
                                       wboffset.as<uint64_t>(), (uint64_t) 0,
                                       (size_t) (nb + 1),
