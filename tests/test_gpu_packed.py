@@ -81,14 +81,16 @@ def test_packed_batch_reproduces_the_golden_lists(V, bits):
                           V.findquerymatches(gi, rcb, 20).fetch())
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(8))
 def test_wildcards_repeats_and_short_reads_packed(V, seed):
     """reads with wildcards travel on the side list; reads cut from repeats
     tie on all key symbols (reference walk through QSrc); lengths that are no
-    multiple of 4 or 32; a text with wildcards and separators"""
+    multiple of 4 or 32; a text with wildcards and separators; rows of more
+    than four words (150 bp and longer: the first pass looks at them through
+    windows) and of more than eight (expanded to bytes on the device)"""
     rng = np.random.default_rng(4200 + seed)
-    m = [100, 37, 64, 121][seed]
-    L = [20, 12, 16, 25][seed]
+    m = [100, 37, 64, 121, 150, 200, 252, 253][seed]
+    L = [20, 12, 16, 25, 20, 30, 18, 22][seed]
     unit = rng.integers(0, 4, 300).astype(np.uint8)
     t = rng.integers(0, 4, 60000).astype(np.uint8)
     for r in range(12):

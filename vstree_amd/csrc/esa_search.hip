@@ -739,8 +739,11 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
   // packed batches (reads at two bits per symbol): first pass, plan and
   // search kernel read the rows; everything else takes the bytes, which are
   // made on the device once per batch
+  // (rows of up to four words -- reads of up to 124 symbols -- come into
+  // registers whole in the first pass; longer ones, 150 bp, are looked at
+  // through windows of their rows there as well)
   const bool rows = queries->rows != nullptr && reduce && deepok &&
-                    queries->roww <= 4;
+                    queries->roww <= 8;
   if (queries->rows != nullptr && !rows)
   {
     if (vsa_queries_bytes(queries, stream) != 0)
@@ -872,7 +875,14 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
     // (both halves of a count stay below 2^32: nq does)
     VSA_HIP(hipMemsetAsync(bcount.as<uint64_t>() + nb, 0, 8, stream));
     tfirst.start();
-    if (rows)
+    if (rows && queries->roww > 4)
+    {
+      k_mum_first<IDX, true, true, true, true>
+          <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+              ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+              wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+              wfmdb.as<uint64_t>(), bcount.as<uint64_t>());
+    } else if (rows)
     {
       k_mum_first<IDX, true, true, true>
           <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
