@@ -846,7 +846,7 @@ def main():
     queries.set_offset(rank * nq)
     V.device_free(dq, dev)
     extras = rank == 0 and world == 1 and not a.quick
-    q150 = None
+    q150 = hq150 = None
     if extras:
         # BASELINE configs[4]: 150 bp reads of the same genome
         p5, s5, st5 = V.synth_query_plan(n, nq, 150)
@@ -856,6 +856,8 @@ def main():
                                                 st5.ctypes.data, nq, 150, dq,
                                                 dev))
         q150 = V.Queries.from_device(dq, nq, 150, dev)
+        hq150 = np.empty(nq * 150, np.uint8)    # (for the rows of -mum below)
+        V.device_download(hq150, dq, dev)
         V.device_free(dq, dev)
     if not extras:
         V.device_free(dg, dev)
@@ -1177,6 +1179,9 @@ def main():
         if extras:
             fams += extra_families(a, V, H, index, queries, q150, host, small,
                                    w, nq, m, L, bytes_per_query, cbytes)
+            out["mum_150bp"] = mum_other_length(V, index, q150, hq150, nq,
+                                                150, L, dev)
+            hq150 = None
             out["end_to_end"] = end_to_end(V, index, dg, n, nq, m, L, dev)
             V.device_free(dg, dev)
         out["roofline_families"] = fams
@@ -1285,6 +1290,36 @@ def extra_families(a, V, H, index, queries, q150, host, small, w, nq, m, L,
         "%d start positions x (154 text + 150 pattern symbols)"
         % s.kernel_searches, traffic_key="k_apm_banded", queries=nq))
     return fams
+
+
+def mum_other_length(V, index, qbytes, hostsymbols, nq, m, L, dev):
+    """the headline step on reads of another length (150 bp, the other common
+    read length: rows of five words, which the first pass looks at through
+    windows): the same timing, a few steps; not the headline"""
+    packed = V.Queries.from_host_packed(hostsymbols, m, dev)
+    out = {}
+    for name, q in (("rows", packed), ("bytes", qbytes)):
+        for _ in range(2):
+            V.findquerymatches(index, q, L, mum=True).close()
+        V.device_synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r = V.findquerymatches(index, q, L, mum=True)
+            st = r.stats()
+            r.close()
+        V.device_synchronize(dev)
+        dt = (time.perf_counter() - t0) / 5
+        out[name] = {"ms_per_step": dt * 1e3, "value": nq / dt,
+                     "search_kernel_ms": st.search_kernel_ms,
+                     "first_pass_ms": st.first_kernel_ms,
+                     "matches": int(st.count)}
+    packed.close()
+    if out["rows"]["matches"] != out["bytes"]["matches"]:
+        raise RuntimeError("bench.py: %d bp reads as rows and as bytes "
+                           "disagree" % m)
+    out["what"] = "vmatch -mum -l %d, %s reads of %d bp, results in HBM" % (
+        L, human(nq), m)
+    return out
 
 
 def end_to_end(V, index, dg, n, nq, m, L, dev):
