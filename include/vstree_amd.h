@@ -203,11 +203,11 @@ int vsa_queries_from_device(const void *device_symbols, uint64_t nq,
   host threads over disjoint pieces of the batch (the side list is numbered
   afterwards, in the order of the reads: the rows do not depend on the number
   of threads).
-  A packed batch is a batch like any other to every engine call.  -mum and
-  -mum cand on an index with deep tables read the rows directly (reads of up
-  to 252 symbols), -complete those of up to 124; the other modes and longer
-  reads make the bytes on the device first (once per batch: 0.3 ms per 10 M
-  reads of 100 symbols).
+  A packed batch is a batch like any other to every engine call.  -complete,
+  -mum and -mum cand on an index with deep tables read the rows directly
+  (reads of up to 252 symbols: whole in registers up to 124, through 16-byte
+  windows of the row beyond); the other modes and longer reads make the bytes
+  on the device first (once per batch: 0.3 ms per 10 M reads of 100 symbols).
 */
 uint32_t vsa_packed_words(uint32_t querylength);
 int vsa_pack_reads(const uint8_t *symbols, uint64_t numofqueries,

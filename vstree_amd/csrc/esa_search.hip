@@ -69,10 +69,11 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
   vsa_dev_set_stream(stream);
   Timer tall(stream), tsearch(stream);
   const DevIndex<IDX> ix = index->view<IDX>();
-  // packed batches: read from their rows by the deep kernel; an index
-  // without deep tables (or reads beyond four words) takes their bytes
+  // packed batches: read from their rows by the deep kernel (whole in
+  // registers up to four words, through windows up to eight); an index
+  // without deep tables, or longer reads, takes their bytes
   const bool rows = queries->rows != nullptr && ix.esa8 != nullptr &&
-                    queries->roww <= 4 && queries->maxlength >= ix.D;
+                    queries->roww <= 8 && queries->maxlength >= ix.D;
   if (queries->rows != nullptr && !rows &&
       vsa_queries_bytes(queries, stream) != 0)
   {
@@ -99,7 +100,12 @@ int run_complete(const vsa_index *index, const vsa_queries *queries,
     const bool staged = ix.esa8 != nullptr && qs.dense != 0 &&
                         qs.symbols != nullptr && qs.uniformlen <= 128 &&
                         (qs.uniformlen & 3u) == 0 && qs.uniformlen >= ix.D;
-    if (rows)
+    if (rows && queries->roww > 4)
+    {
+      k_complete_search<IDX, true, true, true, true>
+          <<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
+              ix, qs, qlimit, left.as<uint64_t>(), count.as<uint64_t>());
+    } else if (rows)
     {
       k_complete_search<IDX, true, true, true>
           <<<gridfor(qlimit), VSA_BLOCK, 0, stream>>>(
@@ -793,6 +799,13 @@ int run_query(const vsa_index *index, const vsa_queries *queries, bool domum,
       {
         // (a packed batch: offset 0 of every read from its row, as -mum does)
         k_mum_first<IDX, true, true, true>
+            <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
+                ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
+                wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
+                wfmdb.as<uint64_t>());
+      } else if (queries->rows != nullptr && queries->roww <= 8)
+      {
+        k_mum_first<IDX, true, true, true, true>
             <<<gridfor(nq), VSA_BLOCK, 0, stream>>>(
                 ix, qs, perquery, searchlength, wcount.as<uint32_t>(),
                 wfirste.as<uint32_t>(), wfmlen.as<uint32_t>(),
